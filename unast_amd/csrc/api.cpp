@@ -1,0 +1,26 @@
+// Host-side glue of the C ABI: error reporting, version/arch query.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "common.h"
+#include "../../include/unast_hip.h"
+
+static thread_local char g_err[512] = "";
+
+int unast_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int unast_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return unast_set_error(UNAST_ERR_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return UNAST_OK;
+}
+
+extern "C" const char* unast_last_error(void) { return g_err; }
+extern "C" int unast_version(void) { return 100; }
+extern "C" const char* unast_arch(void) { return "gfx950"; }

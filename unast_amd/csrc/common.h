@@ -1,0 +1,115 @@
+// Shared device helpers for the UNAST gfx950 kernels (CDNA4 only: wave64, MFMA 16x16x32 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define UNAST_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// Status / error reporting (host side, defined in api.cpp)
+// ---------------------------------------------------------------------------------------------
+enum { UNAST_OK = 0, UNAST_ERR_ARG = -1, UNAST_ERR_LAUNCH = -2, UNAST_ERR_ALIGN = -3 };
+int unast_set_error(int code, const char* fmt, ...);
+int unast_check_launch(const char* what);
+
+#define UNAST_REQUIRE(cond, ...)                                  \
+    do {                                                          \
+        if (!(cond)) return unast_set_error(UNAST_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG for dropout / noise masks: a function of (seed, stream, row, col) only, so the
+// backward pass regenerates the forward mask from the same four integers in any thread layout.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+__device__ __forceinline__ uint32_t rng_row_key(uint32_t seed, uint32_t stream, uint32_t row) {
+    return pcg_hash(row + pcg_hash(stream + pcg_hash(seed)));
+}
+__device__ __forceinline__ uint32_t rng_u32(uint32_t row_key, uint32_t col) { return pcg_hash(col ^ row_key) ; }
+// keep decision for drop probability p encoded as threshold = p * 2^32 (0 => keep everything)
+__device__ __forceinline__ bool rng_keep(uint32_t row_key, uint32_t col, uint32_t thresh) {
+    return rng_u32(row_key, col) >= thresh;
+}
+static inline uint32_t drop_threshold(float p) {
+    if (p <= 0.f) return 0u;
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 -> bf16 operand preparation for MFMA.
+//   NSPLIT==1: one bf16 (round to nearest even).
+//   NSPLIT==3: x = hi + lo with hi = truncated top 16 bits (exact), lo = RNE(x - hi); the product
+//              a*b is then formed as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (fp32 accumulate), which
+//              keeps ~16 mantissa bits per operand.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack_bf16_rne(float a, float b) {
+    f32x2 v = {a, b};
+    bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pack_bf16_trunc(float a, float b) {
+    return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xFFFF0000u);
+}
+template <int NSPLIT>
+__device__ __forceinline__ void split4(const float4& v, u32x2& hi, u32x2& lo) {
+    if (NSPLIT == 1) {
+        hi[0] = pack_bf16_rne(v.x, v.y);
+        hi[1] = pack_bf16_rne(v.z, v.w);
+        lo[0] = 0; lo[1] = 0;
+    } else {
+        hi[0] = pack_bf16_trunc(v.x, v.y);
+        hi[1] = pack_bf16_trunc(v.z, v.w);
+        float rx = v.x - __uint_as_float(__float_as_uint(v.x) & 0xFFFF0000u);
+        float ry = v.y - __uint_as_float(__float_as_uint(v.y) & 0xFFFF0000u);
+        float rz = v.z - __uint_as_float(__float_as_uint(v.z) & 0xFFFF0000u);
+        float rw = v.w - __uint_as_float(__float_as_uint(v.w) & 0xFFFF0000u);
+        lo[0] = pack_bf16_rne(rx, ry);
+        lo[1] = pack_bf16_rne(rz, rw);
+    }
+}
+__device__ __forceinline__ float bf16_bits_to_float(unsigned short b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+__device__ __forceinline__ f32x4 mfma16(const bf16x8_t& a, const bf16x8_t& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// Transposed LDS read (gfx950 ds_read_b64_tr_b16): within each group of 16 lanes, lane 4q+p supplies the
+// address of row q, columns 4p..4p+3 of a 4x16 block of 16-bit elements; lane i receives column i of the
+// four rows (row q in element q).  EXEC must be all ones.
+__device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds_addr));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave / block reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,317 @@
+// Split-bf16 MFMA GEMM for gfx950: C[M,N] = epilogue(alpha * A[M,K] * B[N,K]^T).
+//
+// One kernel template serves every dense contraction of the UNAST train step:
+//   linear forward   Y = X W^T        A K-contiguous,  B K-contiguous
+//   linear dgrad     dX = dY W        A K-contiguous,  B row-contiguous ([K][N])
+//   linear wgrad     dW = dY^T X      A row-contiguous ([K][M]), B row-contiguous, split-K + fp32 atomics
+//   conv1d k5 forward / dgrad / wgrad as implicit GEMM over (tap, channel) with time-shifted row gathers
+//   (TextPrenet src/module.py:199-230 'same' padding, SpeechPostnet src/module.py:155-168 causal padding).
+//
+// Operands live in HBM as fp32; each 128x32 tile is converted on the way into LDS to bf16 (NSPLIT=1) or to a
+// hi/lo bf16 pair (NSPLIT=3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate) so that the contraction keeps
+// ~16 mantissa bits per operand while still running on the bf16 MFMA pipe (v_mfma_f32_16x16x32_bf16).
+// K-contiguous operands are staged as [row][32 k] images (XOR-swizzled 16-B chunks, read with ds_read_b128);
+// row-contiguous operands are staged untransposed as [k][row] images and read with ds_read_b64_tr_b16.
+// 256 threads = 4 waves (2x2), each wave owns a 64x64 sub-tile = 4x4 MFMA tiles, accumulators stay in VGPRs.
+#include "common.h"
+
+#define GBM 128
+#define GBN 128
+#define GBK 32
+#define RC_STRIDE (GBM + 16)                 // bf16 elements per k-row of a row-contiguous image (288 B)
+#define KC_BYTES (GBM * GBK * 2)             // 8192
+#define RC_BYTES (GBK * RC_STRIDE * 2)       // 9216
+
+enum { OP_KC = 0, OP_KC_CONV = 1, OP_RC = 2, OP_RC_CONV_DGRAD = 3, OP_RC_CONV_WGRAD = 4 };
+
+struct GemmParams {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int T, ca, cb, shift, KS;                // implicit-conv geometry
+    const float* bias; const float* R; int ldr; const float* G; int ldg; float gate_scale;
+    float alpha; int beta; int act;
+    uint32_t drop_thresh; float drop_scale; uint32_t seed, stream;
+    int kchunk; int atomic; int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int swz_h(int row) { return (0x1320 >> (((row >> 2) & 3) << 2)) & 3; }
+__device__ __forceinline__ int kc_off(int row, int k) {      // byte offset of element (row,k) in a [128][32] image
+    return row * 64 + ((((k >> 3) ^ swz_h(row))) << 4) + ((k & 7) << 1);
+}
+
+template <int MODE>
+__device__ __forceinline__ float4 load_kc(const GemmParams& p, const float* __restrict__ src, int ld, int nrows,
+                                          int row, int k, int kend, int conv_rb, int conv_rt) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows && k < kend) {
+        if (MODE == OP_KC) {
+            const float* ptr = src + (size_t)row * ld + k;
+            if (k + 3 < kend) {
+                v = *reinterpret_cast<const float4*>(ptr);
+            } else {
+                v.x = ptr[0];
+                if (k + 1 < kend) v.y = ptr[1];
+                if (k + 2 < kend) v.z = ptr[2];
+            }
+        } else {   // OP_KC_CONV: A[(b,t)][(j,c)] = X[b, t + j - shift, c]
+            int j = k / p.ca;
+            int c = k - j * p.ca;
+            int ts = conv_rt + j - p.shift;
+            if (ts >= 0 && ts < p.T) v = *reinterpret_cast<const float4*>(src + (size_t)(conv_rb + ts) * ld + c);
+        }
+    }
+    return v;
+}
+
+template <int MODE>
+__device__ __forceinline__ float4 load_rc(const GemmParams& p, const float* __restrict__ src, int ld, int nrows,
+                                          int row, int k, int kend, int conv_j, int conv_c) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows && k < kend) {
+        if (MODE == OP_RC_CONV_WGRAD) {     // B[(b,t)][(j,c)] = X[b, t + j - shift, c]
+            int b = k / p.T;
+            int tt = k - b * p.T;
+            int ts = tt + conv_j - p.shift;
+            if (ts >= 0 && ts < p.T) v = *reinterpret_cast<const float4*>(src + (size_t)(b * p.T + ts) * ld + conv_c);
+        } else {
+            const float* ptr;
+            if (MODE == OP_RC) {
+                ptr = src + (size_t)k * ld + row;
+            } else {                        // OP_RC_CONV_DGRAD: B[c][(j',o)] = Wp[o][KS-1-j'][c], Wp = [O][KS][C]
+                int jj = k / p.cb;
+                int o = k - jj * p.cb;
+                ptr = src + ((size_t)o * p.KS + (p.KS - 1 - jj)) * nrows + row;
+            }
+            if (row + 3 < nrows) {
+                v = *reinterpret_cast<const float4*>(ptr);
+            } else {
+                v.x = ptr[0];
+                if (row + 1 < nrows) v.y = ptr[1];
+                if (row + 2 < nrows) v.z = ptr[2];
+            }
+        }
+    }
+    return v;
+}
+
+template <int AM, int BMODE, int NSPLIT>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+    constexpr bool A_KC = (AM == OP_KC || AM == OP_KC_CONV);
+    constexpr bool B_KC = (BMODE == OP_KC);
+    constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
+    constexpr int A_BYTES = A_KC ? KC_BYTES : RC_BYTES;
+    constexpr int B_BYTES = B_KC ? KC_BYTES : RC_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(A_BYTES + B_BYTES) * PARTS];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + A_BYTES * PARTS;
+
+    // XCD-aware tile mapping: blocks b and b+8 (same XCD under round-robin dispatch) share the A row panel.
+    const int pid = blockIdx.x;
+    const int G = 8 * p.tiles_n;
+    const int grp = pid / G, rem = pid - grp * G;
+    const int tile_m = grp * 8 + (rem & 7);
+    const int tile_n = rem >> 3;
+    if (tile_m >= p.tiles_m) return;        // whole block exits together (keeps EXEC full for tr reads)
+    const int m0 = tile_m * GBM, n0 = tile_n * GBN;
+    const int kbeg = blockIdx.y * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk = (kend - kbeg + GBK - 1) / GBK;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    // ---- per-thread loader coordinates -------------------------------------------------------
+    int a_rb[4] = {0, 0, 0, 0}, a_rt[4] = {0, 0, 0, 0};   // conv A: batch row base / time index of the 4 tile rows of this thread
+    if (AM == OP_KC_CONV) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = m0 + (t >> 3) + 32 * i;
+            int b = row / p.T;
+            a_rb[i] = b * p.T;
+            a_rt[i] = row - b * p.T;
+        }
+    }
+    int b_cj = 0, b_cc = 0;                 // conv-wgrad B: tap and channel of this thread's 4 columns
+    if (BMODE == OP_RC_CONV_WGRAD) {
+        int row = n0 + (t & 31) * 4;
+        b_cj = row / p.cb;
+        b_cc = row - b_cj * p.cb;
+    }
+
+    float4 ra[4], rb[4];
+    auto load_tiles = [&](int kt) {
+        const int k0 = kbeg + kt * GBK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (A_KC) ra[i] = load_kc<AM>(p, p.A, p.lda, p.M, m0 + (t >> 3) + 32 * i, k0 + (t & 7) * 4, kend, a_rb[i], a_rt[i]);
+            else      ra[i] = load_rc<AM>(p, p.A, p.lda, p.M, m0 + (t & 31) * 4, k0 + (t >> 5) + 8 * i, kend, 0, 0);
+            if (B_KC) rb[i] = load_kc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t >> 3) + 32 * i, k0 + (t & 7) * 4, kend, 0, 0);
+            else      rb[i] = load_rc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t & 31) * 4, k0 + (t >> 5) + 8 * i, kend, b_cj, b_cc);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 hi, lo;
+            split4<NSPLIT>(ra[i], hi, lo);
+            int off = A_KC ? kc_off((t >> 3) + 32 * i, (t & 7) * 4) : (((t >> 5) + 8 * i) * RC_STRIDE + (t & 31) * 4) * 2;
+            *reinterpret_cast<u32x2*>(sA + off) = hi;
+            if (PARTS == 2) *reinterpret_cast<u32x2*>(sA + A_BYTES + off) = lo;
+            split4<NSPLIT>(rb[i], hi, lo);
+            off = B_KC ? kc_off((t >> 3) + 32 * i, (t & 7) * 4) : (((t >> 5) + 8 * i) * RC_STRIDE + (t & 31) * 4) * 2;
+            *reinterpret_cast<u32x2*>(sB + off) = hi;
+            if (PARTS == 2) *reinterpret_cast<u32x2*>(sB + B_BYTES + off) = lo;
+        }
+    };
+    // MFMA operand fragment for the 16-row sub-tile starting at tile row `rbase`: lane holds [row l15][k 8g..8g+7]
+    auto frag = [&](const unsigned char* img, bool kc, int rbase) -> bf16x8_t {
+        if (kc) {
+            int row = rbase + l15;
+            return *reinterpret_cast<const bf16x8_t*>(img + row * 64 + ((g ^ swz_h(row)) << 4));
+        } else {
+            const int q = l15 >> 2, pp = l15 & 3;
+            s16x4 v0 = lds_read_tr16(img + ((8 * g + q) * RC_STRIDE + rbase + 4 * pp) * 2);
+            s16x4 v1 = lds_read_tr16(img + ((8 * g + 4 + q) * RC_STRIDE + rbase + 4 * pp) * 2);
+            s16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            return __builtin_bit_cast(bf16x8_t, v);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) load_tiles(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tiles();
+        __syncthreads();
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        bf16x8_t af[4][PARTS], bfr[4][PARTS];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int s = 0; s < PARTS; ++s) {
+                af[i][s] = frag(sA + s * A_BYTES, A_KC, wm * 64 + i * 16);
+                bfr[i][s] = frag(sB + s * B_BYTES, B_KC, wn * 64 + i * 16);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // swapped operands: the B tile is the MFMA "A" (rows = n), so each lane ends up with 4 consecutive n
+                if (NSPLIT == 3) {
+                    acc[i][j] = mfma16(bfr[j][PARTS - 1], af[i][0], acc[i][j]);
+                    acc[i][j] = mfma16(bfr[j][0], af[i][PARTS - 1], acc[i][j]);
+                }
+                acc[i][j] = mfma16(bfr[j][0], af[i][0], acc[i][j]);
+            }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m = ..+l15][n = ..+4g .. 4g+3] --------------------------------------
+    const bool first_split = (blockIdx.y == 0);
+    const bool vec_ok = ((p.ldc & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + l15;
+        if (m >= p.M) continue;
+        uint32_t rkey = 0;
+        if (p.drop_thresh) rkey = rng_row_key(p.seed, p.stream, (uint32_t)m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * g;
+            if (n >= p.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = n + r;
+                if (nn >= p.N) break;
+                float x = v[r] * p.alpha;
+                if (p.bias && first_split) x += p.bias[nn];
+                if (p.act == 1) x = fmaxf(x, 0.f);
+                if (p.drop_thresh) x = rng_keep(rkey, (uint32_t)nn, p.drop_thresh) ? x * p.drop_scale : 0.f;
+                if (p.G) x = (p.G[(size_t)m * p.ldg + nn] > 0.f) ? x * p.gate_scale : 0.f;
+                if (p.R && first_split) x += p.R[(size_t)m * p.ldr + nn];
+                v[r] = x;
+            }
+            float* cp = p.C + (size_t)m * p.ldc + n;
+            if (p.atomic) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) atomicAdd(cp + r, v[r]);
+            } else if (vec_ok && n + 3 < p.N) {
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.beta) {
+                    float4 c = *reinterpret_cast<const float4*>(cp);
+                    o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+                }
+                *reinterpret_cast<float4*>(cp) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) cp[r] = p.beta ? cp[r] + v[r] : v[r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host launcher / C ABI
+// ---------------------------------------------------------------------------------------------
+template <int AM, int BMODE>
+static void launch_split(const GemmParams& p, int nsplit, dim3 grid, hipStream_t s) {
+    if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3>), grid, dim3(256), 0, s, p);
+    else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1>), grid, dim3(256), 0, s, p);
+}
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
+                          const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                          int M, int N, int K,
+                          int conv_T, int conv_ca, int conv_cb, int conv_shift,
+                          const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale,
+                          float alpha, int beta, int act,
+                          float drop_p, unsigned int seed, unsigned int stream_id,
+                          int splitk, hipStream_t stream) {
+    UNAST_REQUIRE(A && B && C, "unast_gemm: null operand");
+    UNAST_REQUIRE(M > 0 && N > 0 && K > 0, "unast_gemm: bad dims M=%d N=%d K=%d", M, N, K);
+    UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_gemm: nsplit must be 1 or 3");
+    UNAST_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C), "unast_gemm: operands must be 16-byte aligned");
+    UNAST_REQUIRE((lda & 3) == 0 && (ldb & 3) == 0, "unast_gemm: lda/ldb must be multiples of 4 (got %d, %d)", lda, ldb);
+    UNAST_REQUIRE(splitk >= 1, "unast_gemm: splitk >= 1");
+    UNAST_REQUIRE(!(splitk > 1 && (act || drop_p > 0.f || G || beta == 0)),
+                  "unast_gemm: split-K accumulates atomically into C (beta=1) and allows only bias/residual epilogues");
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.T = conv_T > 0 ? conv_T : 1; p.ca = conv_ca > 0 ? conv_ca : 1; p.cb = conv_cb > 0 ? conv_cb : 1;
+    p.shift = conv_shift; p.KS = 5;
+    p.bias = bias; p.R = R; p.ldr = ldr; p.G = G; p.ldg = ldg; p.gate_scale = gate_scale;
+    p.alpha = alpha; p.beta = beta; p.act = act;
+    p.drop_thresh = drop_threshold(drop_p); p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    p.seed = seed; p.stream = stream_id;
+    p.tiles_m = (M + GBM - 1) / GBM; p.tiles_n = (N + GBN - 1) / GBN;
+    int ksteps = (K + GBK - 1) / GBK;
+    if (splitk > ksteps) splitk = ksteps;
+    int steps_per = (ksteps + splitk - 1) / splitk;
+    p.kchunk = steps_per * GBK;
+    splitk = (ksteps + steps_per - 1) / steps_per;
+    p.atomic = splitk > 1 ? 1 : 0;
+    if (a_mode == OP_KC_CONV) UNAST_REQUIRE((conv_ca & 3) == 0 && K == 5 * conv_ca && M % p.T == 0, "unast_gemm: bad conv A geometry");
+    if (b_mode == OP_RC_CONV_DGRAD) UNAST_REQUIRE(K == 5 * conv_cb, "unast_gemm: bad conv dgrad geometry");
+    if (b_mode == OP_RC_CONV_WGRAD) UNAST_REQUIRE((conv_cb & 3) == 0 && N == 5 * conv_cb && K % p.T == 0, "unast_gemm: bad conv wgrad geometry");
+    dim3 grid(((p.tiles_m + 7) / 8) * 8 * p.tiles_n, splitk, 1);
+    if (a_mode == OP_KC && b_mode == OP_KC) launch_split<OP_KC, OP_KC>(p, nsplit, grid, stream);
+    else if (a_mode == OP_KC && b_mode == OP_RC) launch_split<OP_KC, OP_RC>(p, nsplit, grid, stream);
+    else if (a_mode == OP_RC && b_mode == OP_RC) launch_split<OP_RC, OP_RC>(p, nsplit, grid, stream);
+    else if (a_mode == OP_KC_CONV && b_mode == OP_KC) launch_split<OP_KC_CONV, OP_KC>(p, nsplit, grid, stream);
+    else if (a_mode == OP_KC_CONV && b_mode == OP_RC_CONV_DGRAD) launch_split<OP_KC_CONV, OP_RC_CONV_DGRAD>(p, nsplit, grid, stream);
+    else if (a_mode == OP_RC && b_mode == OP_RC_CONV_WGRAD) launch_split<OP_RC, OP_RC_CONV_WGRAD>(p, nsplit, grid, stream);
+    else return unast_set_error(UNAST_ERR_ARG, "unast_gemm: unsupported operand mode pair (%d,%d)", a_mode, b_mode);
+    return unast_check_launch("unast_gemm");
+}
