@@ -42,6 +42,105 @@ int unast_gemm(int a_mode, int b_mode, int nsplit,
                float drop_p, unsigned int seed, unsigned int stream_id,
                int splitk, hipStream_t stream);
 
+/* Fused multi-head attention core (head_dim 64), flash-style.  Replaces the softmax(QK^T/sqrt(d)+mask) -> dropout -> V
+ * core of torch.nn.MultiheadAttention inside torch.nn.TransformerEncoderLayer/DecoderLayer
+ * (src/module.py:273-274, 286-287; masks built at src/network.py:404-415, src/utils.py:77-83).
+ * Q [B,Tq,ldq], K/V [B,Tk,ld*]: head h occupies columns [64h, 64h+64).  Keys >= lens_k[b] are masked (lens_k may be
+ * NULL); causal masks key > query.  O [B,Tq,ldo] (heads concatenated), LSE [B,H,Tq] saved for the backward. */
+int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                   float* LSE, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
+                   float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);
+/* Backward of the above (autograd of the same torch call sites): dQ, dK, dV from dO; delta_ws is [B,H,Tq] scratch. */
+int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                   const float* dO, int lddo, const float* LSE, float* delta_ws, float* dQ, int lddq, float* dK, int lddk,
+                   float* dV, int lddv, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
+                   float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);
+
+/* LayerNorm(eps) of the post-LN transformer blocks (norm1/2/3 inside torch layers, src/module.py:273-274,286-287).
+ * bwd: dz (and optionally dz_drop = dz * dropout mask/(1-p), the gradient of the dropped sub-layer output);
+ * dgamma/dbeta are ACCUMULATED (+=) and may be NULL for frozen parameters. */
+int unast_layernorm_fwd(const float* z, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int rows, int C, float eps, hipStream_t stream);
+int unast_layernorm_bwd(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd,
+                        float* dz, float* dz_drop, float* dgamma, float* dbeta, int rows, int C,
+                        float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);
+
+/* Column sums sum[c] += sum_r x[r,c] (bias gradients of every nn.Linear/nn.Conv1d on the path). */
+int unast_colsum_f32(const float* x, int ldx, int rows, int C, float* sum, hipStream_t stream);
+
+/* Train-mode BatchNorm1d + activation (1 relu, 2 tanh) + dropout over [rows=B*T, C]: TextPrenet.forward_fcn
+ * (src/module.py:223-230) and SpeechPostnet.forward (src/module.py:162-165).  Updates running stats (momentum,
+ * unbiased variance) when running_mean != NULL.  ws: 2*C doubles of scratch.
+ * bwd: dy_inout is overwritten with d(pre-activation); dgamma/dbeta accumulated (may be NULL). */
+int unast_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                 float* running_mean, float* running_var, double* ws, int rows, int C,
+                 float eps, float momentum, int act, float drop_p, unsigned int seed, unsigned int stream_id,
+                 hipStream_t stream);
+int unast_bn_bwd(float* dy_inout, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                 float* dx, float* dgamma, float* dbeta, double* ws, int rows, int C, int act,
+                 float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);
+
+/* nn.Embedding(padding_idx=0) + emb_dropout + noise_fn (src/module.py:189,226; src/network.py:429-438, 483-487;
+ * src/utils.py:40-49).  shift_sos >= 0 builds the decoder input [SOS, ids[:-1]] on the fly. dE is accumulated. */
+int unast_embed_fwd(const int64_t* ids, const float* E, float* out, int rows, int T, int D, int shift_sos,
+                    float drop_p, unsigned int seed, unsigned int stream_id, float noise_p, unsigned int noise_stream,
+                    hipStream_t stream);
+int unast_embed_bwd(const int64_t* ids, const float* dout, float* dE, int rows, int T, int D, int vocab, int shift_sos,
+                    int padding_idx, float drop_p, unsigned int seed, unsigned int stream_id, float noise_p,
+                    unsigned int noise_stream, hipStream_t stream);
+
+/* PositionalEncoding.forward (src/module.py:265-267): y = dropout(x*scale + pe[t]); bwd optionally gated by gate>0. */
+int unast_posenc_fwd(const float* x, const float* pe, float* y, int rows, int T, int D, float scale, float drop_p,
+                     unsigned int seed, unsigned int stream_id, hipStream_t stream);
+int unast_posenc_bwd(const float* dy, const float* gate, float* dx, int rows, int D, float scale, float drop_p,
+                     unsigned int seed, unsigned int stream_id, hipStream_t stream);
+
+/* noise_fn (src/utils.py:40-49): zero whole timesteps with probability p, no rescale. */
+int unast_rowmask(const float* x, float* y, int rows, int D, float p, unsigned int seed, unsigned int stream_id,
+                  hipStream_t stream);
+/* a += b : gradient accumulation for activations consumed by several ops (autograd's implicit add). */
+int unast_add_inplace(float* a, const float* b, int64_t n, hipStream_t stream);
+/* specaugment (src/utils.py:51-75), including its quirk of masking two TIME spans and no frequency columns. */
+int unast_specaugment(const float* mel, const int* lens, float* out, int B, int T, int M, int freq_mask, int time_mask,
+                      unsigned int seed, unsigned int stream_id, hipStream_t stream);
+/* discriminator_shuffle_batch (src/train.py:296-329): pad to common T, concat on batch, permute; and its backward. */
+int unast_disc_gather(const float* t_hid, const float* s_hid, const int* t_len, const int* s_len, const int64_t* perm,
+                      float* out, int* out_len, int B, int Tt, int Ts, int D, hipStream_t stream);
+int unast_disc_scatter(const float* dout, const int64_t* perm, float* dt_hid, float* ds_hid, int B, int Tt, int Ts, int D,
+                       hipStream_t stream);
+
+/* speech_loss (src/train.py:100-103, 113-122): head = [pre-net mel (M cols) | stop logit | pad] with row stride ldh.
+ * fwd writes loss[0]; bwd writes d_head (same layout) and d_post scaled by the device scalar *gscale. ws: 3 doubles. */
+int unast_speech_loss_fwd(const float* gold, const float* head, int ldh, const float* post, const int* lens, int B, int T, int M,
+                          float eos_weight, double* ws, float* loss, hipStream_t stream);
+int unast_speech_loss_bwd(const float* gold, const float* head, int ldh, const float* post, const int* lens, int B, int T, int M,
+                          float eos_weight, const float* gscale, float* d_head, float* d_post, hipStream_t stream);
+/* text_loss (src/train.py:105-111): weighted CE, ignore_index 0, EOS(2) weight. ws: 2 doubles kept for the backward. */
+int unast_text_loss_fwd(const float* logits, int ldl, const int64_t* gold, int rows, int V, float eos_weight,
+                        double* ws, float* loss, hipStream_t stream);
+int unast_text_loss_bwd(const float* logits, int ldl, const int64_t* gold, int rows, int V, float eos_weight, const double* ws,
+                        const float* gscale, float* dlogits, hipStream_t stream);
+/* discriminator_loss + discriminator_target (src/train.py:147-164, 319-320): BCE-with-logits against smoothed targets
+ * derived from perm (rows < B are text); flip=1 for the generator phase.  loss/dlogits may be NULL. */
+int unast_disc_bce(const float* logits, const int64_t* perm, int n, int B, int flip, float smoothing, const float* gscale,
+                   float* loss, float* dlogits, hipStream_t stream);
+
+/* Recurrent part of nn.LSTM over packed sequences (src/module.py:306, 315-316), hidden 64, gate order i,f,g,o.
+ * xproj [Bd,T,ndir*256] = X W_ih^T (no bias), y [Bd,T,ndir*64] and hprev pre-zeroed by the caller; gates/cs saved. */
+int unast_lstm_fwd(const float* xproj, const float* whh, const float* b_ih, const float* b_hh, const int* lens, float* y, float* gates,
+                   float* cs, float* hprev, float* hfinal, int Bd, int T, int ndir, int hidden, int64_t whh_dir_stride,
+                   int64_t bias_dir_stride, hipStream_t stream);
+int unast_lstm_bwd(const float* dy, const float* dhfinal, const float* whh, const float* gates, const float* cs, const int* lens,
+                   float* dgates, int Bd, int T, int ndir, int hidden, int64_t whh_dir_stride, hipStream_t stream);
+/* LeakyReLU(slope)+Dropout of LSTMDiscriminator / Discriminator (src/network.py:160-170, 179-186); dy != NULL => backward. */
+int unast_leaky_dropout(const float* x, const float* dy, float* out, int rows, int D, float slope, float drop_p, unsigned int seed,
+                        unsigned int stream_id, hipStream_t stream);
+
+/* optimizer_step (src/train.py:358-363): clip_grad_norm_ + torch.optim.AdamW over flat fp32 buffers. */
+int unast_sumsq(const float* g, int64_t n, double* out, hipStream_t stream);
+int unast_adamw(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
+                float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,529 @@
+// Flash-style multi-head attention for gfx950 (head_dim 64): forward, dQ and dK/dV kernels.
+// Replaces torch.nn.MultiheadAttention's softmax(QK^T/sqrt(d) + mask) -> dropout -> .V core inside
+// torch.nn.TransformerEncoderLayer/DecoderLayer (src/module.py:273-274, 286-287; semantics SURVEY.md Appendix A):
+// additive -inf mask = key >= lens_k[b] (key padding) OR key > query (causal); padded QUERIES are not masked.
+// No T x T tensor ever reaches HBM: K/V tiles are staged in LDS as bf16 (split hi/lo when NSPLIT==3), scores and
+// probabilities live in MFMA accumulators, online softmax statistics are per-lane.
+//
+// Layout trick (16x16x32 bf16 MFMA, C/D: col = lane&15, row = 4*(lane>>4)+reg):
+//   forward / dQ kernel: S^T[key,q] = K.Q^T puts the QUERY on the lane, so max/sum over keys is registers + two
+//   shuffles, and the P^T accumulators of two stacked key sub-tiles are directly the B operand of O^T = V^T.P^T
+//   (k-slot j of lane-group g = key 4g+j of sub-tile 2u for j<4, of sub-tile 2u+1 for j>=4); V^T comes from
+//   ds_read_b64_tr_b16 on the untransposed [key][d] image with the same key permutation.
+//   dK/dV kernel: S[q,key] = Q.K^T puts the KEY on the lane; P and dS accumulators are then the B operands of
+//   dV^T = dO^T.P and dK^T = Q^T.dS, with dO^T / Q^T read transposed from the same [q][d] LDS images that feed S, dP.
+#include "common.h"
+
+#define HD 64
+#define ALD 72                     // bf16 elements per LDS image row (64 + 8 pad) = 144 B
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define NEG_BIG (-1.0e30f)
+
+struct AttnParams {
+    const float* Q; const float* K; const float* V; int ldq, ldk, ldv;
+    float* O; int ldo;                 // fwd: output; dq mode: dQ output
+    float* LSE;                        // [B,H,Tq]  fwd: written; bwd: read
+    const float* dO; int lddo;         // bwd
+    const float* Delta;                // [B,H,Tq]  bwd
+    float* dK; float* dV; int lddk, lddv;
+    const int* lens_k;
+    int B, H, Tq, Tk, causal;
+    float scale;
+    uint32_t drop_thresh; float drop_scale; uint32_t seed, stream;
+};
+
+template <int NSPLIT>
+__device__ __forceinline__ void split8(const float4& a, const float4& b, bf16x8_t& hi, bf16x8_t& lo) {
+    u32x2 h0, l0, h1, l1;
+    split4<NSPLIT>(a, h0, l0);
+    split4<NSPLIT>(b, h1, l1);
+    u32x4 h = {h0[0], h0[1], h1[0], h1[1]}, l = {l0[0], l0[1], l1[0], l1[1]};
+    hi = __builtin_bit_cast(bf16x8_t, h);
+    lo = __builtin_bit_cast(bf16x8_t, l);
+}
+
+// 8 fp32 values (two accumulator quads) -> hi/lo bf16x8 operand fragments
+template <int NSPLIT>
+__device__ __forceinline__ void pack_acc(const f32x4& a, const f32x4& b, bf16x8_t& hi, bf16x8_t& lo) {
+    split8<NSPLIT>(make_float4(a[0], a[1], a[2], a[3]), make_float4(b[0], b[1], b[2], b[3]), hi, lo);
+}
+
+// fragment [row = r0 + (lane&15)][k = 32*kst + 8g .. +7] of a [rows][ALD] image
+__device__ __forceinline__ bf16x8_t row_frag(const unsigned char* img, int r0, int kst, int l15, int g) {
+    return *reinterpret_cast<const bf16x8_t*>(img + ((r0 + l15) * ALD + 32 * kst + 8 * g) * 2);
+}
+// transposed fragment: lane gets [col = c0 + (lane&15)][k-slots: rows k0+4g+0..3 then k0+16+4g+0..3]
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* img, int k0, int c0, int l15, int g) {
+    const int q = l15 >> 2, p = l15 & 3;
+    s16x4 v0 = lds_read_tr16(img + ((k0 + 4 * g + q) * ALD + c0 + 4 * p) * 2);
+    s16x4 v1 = lds_read_tr16(img + ((k0 + 16 + 4 * g + q) * ALD + c0 + 4 * p) * 2);
+    s16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int NSPLIT>
+__device__ __forceinline__ f32x4 mma3(const bf16x8_t& ah, const bf16x8_t& al, const bf16x8_t& bh, const bf16x8_t& bl, f32x4 c) {
+    if (NSPLIT == 3) {
+        c = mfma16(al, bh, c);
+        c = mfma16(ah, bl, c);
+    }
+    return mfma16(ah, bh, c);
+}
+
+// global [rows x 64] fp32 tile -> registers (NF float4 per thread); rows >= rows_valid read as zero
+template <int NROWS>
+__device__ __forceinline__ void tile_load(const float* __restrict__ src, int ld, int rows_valid, float4 (&r)[NROWS / 16], int t) {
+#pragma unroll
+    for (int i = 0; i < NROWS / 16; ++i) {
+        const int idx = t + 256 * i;
+        const int row = idx >> 4, dq = (idx & 15) * 4;
+        r[i] = (row < rows_valid) ? *reinterpret_cast<const float4*>(src + (size_t)row * ld + dq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int NROWS, int NSPLIT>
+__device__ __forceinline__ void tile_store(const float4 (&r)[NROWS / 16], unsigned char* hi_img, unsigned char* lo_img, int t) {
+#pragma unroll
+    for (int i = 0; i < NROWS / 16; ++i) {
+        const int idx = t + 256 * i;
+        const int row = idx >> 4, dq = (idx & 15) * 4;
+        u32x2 hi, lo;
+        split4<NSPLIT>(r[i], hi, lo);
+        *reinterpret_cast<u32x2*>(hi_img + (row * ALD + dq) * 2) = hi;
+        if (NSPLIT == 3) *reinterpret_cast<u32x2*>(lo_img + (row * ALD + dq) * 2) = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// MODE 0: forward (O, LSE).  MODE 1: dQ (recomputes P from LSE; dQ = scale * dS.K).
+// grid (ceil(Tq/128), H, B), 256 threads; wave w owns queries [128*bx + 32w, +32).
+// ------------------------------------------------------------------------------------------------------------
+template <int NSPLIT, int MODE>
+__global__ __launch_bounds__(256) void attn_q_kernel(const AttnParams p) {
+    constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
+    constexpr int IMG = 64 * ALD * 2;                         // one 64-row image
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PARTS * IMG];
+    unsigned char* sK[2] = {smem, smem + (PARTS - 1) * IMG};
+    unsigned char* sV[2] = {smem + PARTS * IMG, smem + PARTS * IMG + (PARTS - 1) * IMG};
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int qblk = blockIdx.x * 128;
+    const int q0 = qblk + wave * 32;
+    const int klen = p.lens_k ? min(p.Tk, p.lens_k[b]) : p.Tk;
+    int kmax = klen;
+    if (p.causal) kmax = min(kmax, qblk + 128);
+    const int nkt = (kmax + 63) / 64;
+
+    const float* Qb = p.Q + (size_t)b * p.Tq * p.ldq + h * HD;
+    const float* Kb = p.K + (size_t)b * p.Tk * p.ldk + h * HD;
+    const float* Vb = p.V + (size_t)b * p.Tk * p.ldv + h * HD;
+    const float sc = p.scale * LOG2E;
+
+    // per-wave query-side operand fragments: lane holds X[q = q0+16qs+l15][d = 32kst+8g..+7]
+    bf16x8_t qf[2][2][PARTS], dof[2][2][PARTS];
+    float lse2[2] = {0.f, 0.f}, delta[2] = {0.f, 0.f};
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int q = q0 + 16 * qs + l15;
+        const bool ok = q < p.Tq;
+#pragma unroll
+        for (int kst = 0; kst < 2; ++kst) {
+            float4 a = make_float4(0, 0, 0, 0), c = a;
+            if (ok) {
+                const float* src = Qb + (size_t)q * p.ldq + 32 * kst + 8 * g;
+                a = *reinterpret_cast<const float4*>(src);
+                c = *reinterpret_cast<const float4*>(src + 4);
+            }
+            bf16x8_t hi, lo;
+            split8<NSPLIT>(a, c, hi, lo);
+            qf[qs][kst][0] = hi;
+            if (PARTS == 2) qf[qs][kst][PARTS - 1] = lo;
+            if (MODE == 1) {
+                a = make_float4(0, 0, 0, 0); c = a;
+                if (ok) {
+                    const float* src = p.dO + ((size_t)b * p.Tq + q) * p.lddo + h * HD + 32 * kst + 8 * g;
+                    a = *reinterpret_cast<const float4*>(src);
+                    c = *reinterpret_cast<const float4*>(src + 4);
+                }
+                split8<NSPLIT>(a, c, hi, lo);
+                dof[qs][kst][0] = hi;
+                if (PARTS == 2) dof[qs][kst][PARTS - 1] = lo;
+            }
+        }
+        if (MODE == 1 && ok) {
+            lse2[qs] = p.LSE[((size_t)b * p.H + h) * p.Tq + q] * LOG2E;
+            delta[qs] = p.Delta[((size_t)b * p.H + h) * p.Tq + q];
+        }
+    }
+
+    float m[2] = {NEG_BIG, NEG_BIG}, lsum[2] = {0.f, 0.f};
+    f32x4 o[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) o[dt][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 rk[4], rv[4];
+    if (nkt > 0) {
+        tile_load<64>(Kb, p.ldk, min(64, p.Tk), rk, t);
+        tile_load<64>(Vb, p.ldv, min(64, p.Tk), rv, t);
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        tile_store<64, NSPLIT>(rk, sK[0], sK[PARTS - 1], t);
+        tile_store<64, NSPLIT>(rv, sV[0], sV[PARTS - 1], t);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            const int kr = (kt + 1) * 64;
+            tile_load<64>(Kb + (size_t)kr * p.ldk, p.ldk, min(64, p.Tk - kr), rk, t);
+            tile_load<64>(Vb + (size_t)kr * p.ldv, p.ldv, min(64, p.Tk - kr), rv, t);
+        }
+        // ---- S^T[key,q] (and dP^T in dQ mode) -----------------------------------------------------------
+        f32x4 s[4][2], dp[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) { s[ks][qs] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[ks][qs] = s[ks][qs]; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int kst = 0; kst < 2; ++kst) {
+                const bf16x8_t kh = row_frag(sK[0], 16 * ks, kst, l15, g);
+                const bf16x8_t kl = (PARTS == 2) ? row_frag(sK[PARTS - 1], 16 * ks, kst, l15, g) : kh;
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) s[ks][qs] = mma3<NSPLIT>(kh, kl, qf[qs][kst][0], qf[qs][kst][PARTS - 1], s[ks][qs]);
+                if (MODE == 1) {
+                    const bf16x8_t vh = row_frag(sV[0], 16 * ks, kst, l15, g);
+                    const bf16x8_t vl = (PARTS == 2) ? row_frag(sV[PARTS - 1], 16 * ks, kst, l15, g) : vh;
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs) dp[ks][qs] = mma3<NSPLIT>(vh, vl, dof[qs][kst][0], dof[qs][kst][PARTS - 1], dp[ks][qs]);
+                }
+            }
+        // ---- softmax (fwd: online; dQ: from saved LSE) ---------------------------------------------------
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            const int q = q0 + 16 * qs + l15;
+            const uint32_t rkey = p.drop_thresh ? rng_row_key(p.seed, p.stream, (uint32_t)(((size_t)b * p.H + h) * p.Tq + q)) : 0u;
+            float mref;
+            if (MODE == 0) {
+                float tmax = NEG_BIG;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 64 + 16 * ks + 4 * g + r;
+                        const bool valid = key < klen && (!p.causal || key <= q);
+                        const float v = valid ? s[ks][qs][r] * sc : NEG_BIG;
+                        s[ks][qs][r] = v;
+                        tmax = fmaxf(tmax, v);
+                    }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float mnew = fmaxf(m[qs], tmax);
+                const float alpha = exp2f(m[qs] - mnew);
+                m[qs] = mnew;
+                mref = mnew;
+                lsum[qs] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { o[dt][qs][0] *= alpha; o[dt][qs][1] *= alpha; o[dt][qs][2] *= alpha; o[dt][qs][3] *= alpha; }
+            } else {
+                mref = lse2[qs];
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 64 + 16 * ks + 4 * g + r;
+                    float pv;
+                    if (MODE == 0) {
+                        const float v = s[ks][qs][r];
+                        pv = (v > 0.5f * NEG_BIG) ? exp2f(v - mref) : 0.f;
+                        rs += pv;
+                        if (p.drop_thresh) pv = rng_keep(rkey, (uint32_t)key, p.drop_thresh) ? pv * p.drop_scale : 0.f;
+                        s[ks][qs][r] = pv;
+                    } else {
+                        const bool valid = key < klen && (!p.causal || key <= q) && q < p.Tq;
+                        pv = valid ? exp2f(s[ks][qs][r] * sc - mref) : 0.f;
+                        float dpe = dp[ks][qs][r];
+                        if (p.drop_thresh) dpe = rng_keep(rkey, (uint32_t)key, p.drop_thresh) ? dpe * p.drop_scale : 0.f;
+                        s[ks][qs][r] = pv * (dpe - delta[qs]);           // dS^T
+                    }
+                }
+            if (MODE == 0) {
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                lsum[qs] += rs;
+            }
+        }
+        // ---- O^T += V^T . P^T   (dQ mode: dQ^T += K^T . dS^T) ---------------------------------------------
+        unsigned char* const* sX = (MODE == 0) ? sV : sK;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8_t pf[2][PARTS];
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                bf16x8_t hi, lo;
+                pack_acc<NSPLIT>(s[2 * u][qs], s[2 * u + 1][qs], hi, lo);
+                pf[qs][0] = hi;
+                if (PARTS == 2) pf[qs][PARTS - 1] = lo;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8_t xh = tr_frag(sX[0], 32 * u, 16 * dt, l15, g);
+                const bf16x8_t xl = (PARTS == 2) ? tr_frag(sX[PARTS - 1], 32 * u, 16 * dt, l15, g) : xh;
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) o[dt][qs] = mma3<NSPLIT>(xh, xl, pf[qs][0], pf[qs][PARTS - 1], o[dt][qs]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds O^T[d = 16dt+4g+r][q = q0+16qs+l15] ------------------------------------------
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int q = q0 + 16 * qs + l15;
+        if (q >= p.Tq) continue;
+        const float f = (MODE == 0) ? (lsum[qs] > 0.f ? 1.f / lsum[qs] : 0.f) : p.scale;
+        float* dst = p.O + ((size_t)b * p.Tq + q) * p.ldo + h * HD + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<float4*>(dst + 16 * dt) = make_float4(o[dt][qs][0] * f, o[dt][qs][1] * f, o[dt][qs][2] * f, o[dt][qs][3] * f);
+        if (MODE == 0 && g == 0) p.LSE[((size_t)b * p.H + h) * p.Tq + q] = (m[qs] + log2f(lsum[qs])) * LN2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dK / dV.  grid (ceil(Tk/128), H, B); wave w owns keys [128*bx + 32w, +32) and keeps dK^T, dV^T [64 x 32] in
+// accumulators while the workgroup sweeps 32-query tiles of Q and dO through LDS.
+// ------------------------------------------------------------------------------------------------------------
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnParams p) {
+    constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
+    constexpr int IMG = 32 * ALD * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PARTS * IMG];
+    unsigned char* sQ[2] = {smem, smem + (PARTS - 1) * IMG};
+    unsigned char* sD[2] = {smem + PARTS * IMG, smem + PARTS * IMG + (PARTS - 1) * IMG};
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int kblk = blockIdx.x * 128;
+    const int k0 = kblk + wave * 32;
+    const int klen = p.lens_k ? min(p.Tk, p.lens_k[b]) : p.Tk;
+    const float sc = p.scale * LOG2E;
+    const float* Qb = p.Q + (size_t)b * p.Tq * p.ldq + h * HD;
+    const float* Kb = p.K + (size_t)b * p.Tk * p.ldk + h * HD;
+    const float* Vb = p.V + (size_t)b * p.Tk * p.ldv + h * HD;
+    const float* dOb = p.dO + (size_t)b * p.Tq * p.lddo + h * HD;
+    const float* lseb = p.LSE + ((size_t)b * p.H + h) * p.Tq;
+    const float* delb = p.Delta + ((size_t)b * p.H + h) * p.Tq;
+
+    // key-side operand fragments in registers: lane holds X[key = k0+16ks+l15][d = 32kst+8g..+7]
+    bf16x8_t kf[2][2][PARTS], vf[2][2][PARTS];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int key = k0 + 16 * ks + l15;
+        const bool ok = key < p.Tk;
+#pragma unroll
+        for (int kst = 0; kst < 2; ++kst) {
+            float4 a = make_float4(0, 0, 0, 0), c = a, a2 = a, c2 = a;
+            if (ok) {
+                const float* src = Kb + (size_t)key * p.ldk + 32 * kst + 8 * g;
+                a = *reinterpret_cast<const float4*>(src); c = *reinterpret_cast<const float4*>(src + 4);
+                const float* sv = Vb + (size_t)key * p.ldv + 32 * kst + 8 * g;
+                a2 = *reinterpret_cast<const float4*>(sv); c2 = *reinterpret_cast<const float4*>(sv + 4);
+            }
+            bf16x8_t hi, lo;
+            split8<NSPLIT>(a, c, hi, lo);
+            kf[ks][kst][0] = hi; if (PARTS == 2) kf[ks][kst][PARTS - 1] = lo;
+            split8<NSPLIT>(a2, c2, hi, lo);
+            vf[ks][kst][0] = hi; if (PARTS == 2) vf[ks][kst][PARTS - 1] = lo;
+        }
+    }
+    f32x4 dk[4][2], dv[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { dk[dt][ks] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][ks] = dk[dt][ks]; }
+
+    const bool block_live = kblk < klen;                    // all keys of the block masked -> gradients are zero
+    const int qt_begin = p.causal ? (kblk / 32) : 0;
+    const int qt_end = block_live ? (p.Tq + 31) / 32 : qt_begin;
+    float4 rq[2], rd[2];
+    if (qt_begin < qt_end) {
+        tile_load<32>(Qb + (size_t)qt_begin * 32 * p.ldq, p.ldq, min(32, p.Tq - qt_begin * 32), rq, t);
+        tile_load<32>(dOb + (size_t)qt_begin * 32 * p.lddo, p.lddo, min(32, p.Tq - qt_begin * 32), rd, t);
+    }
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+        tile_store<32, NSPLIT>(rq, sQ[0], sQ[PARTS - 1], t);
+        tile_store<32, NSPLIT>(rd, sD[0], sD[PARTS - 1], t);
+        __syncthreads();
+        if (qt + 1 < qt_end) {
+            const int qr = (qt + 1) * 32;
+            tile_load<32>(Qb + (size_t)qr * p.ldq, p.ldq, min(32, p.Tq - qr), rq, t);
+            tile_load<32>(dOb + (size_t)qr * p.lddo, p.lddo, min(32, p.Tq - qr), rd, t);
+        }
+        // ---- S[q,key], dP[q,key] --------------------------------------------------------------------------
+        f32x4 s[2][2], dp[2][2];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { s[qs][ks] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[qs][ks] = s[qs][ks]; }
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int kst = 0; kst < 2; ++kst) {
+                const bf16x8_t qh = row_frag(sQ[0], 16 * qs, kst, l15, g);
+                const bf16x8_t ql = (PARTS == 2) ? row_frag(sQ[PARTS - 1], 16 * qs, kst, l15, g) : qh;
+                const bf16x8_t dh = row_frag(sD[0], 16 * qs, kst, l15, g);
+                const bf16x8_t dl = (PARTS == 2) ? row_frag(sD[PARTS - 1], 16 * qs, kst, l15, g) : dh;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    s[qs][ks] = mma3<NSPLIT>(qh, ql, kf[ks][kst][0], kf[ks][kst][PARTS - 1], s[qs][ks]);
+                    dp[qs][ks] = mma3<NSPLIT>(dh, dl, vf[ks][kst][0], vf[ks][kst][PARTS - 1], dp[qs][ks]);
+                }
+            }
+        // ---- P (dropped) and dS; lane: key = k0+16ks+l15, q = 32qt+16qs+4g+r ------------------------------
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = qt * 32 + 16 * qs + 4 * g + r;
+                const bool qok = q < p.Tq;
+                const float l2 = qok ? lseb[q] * LOG2E : 0.f;
+                const float de = qok ? delb[q] : 0.f;
+                const uint32_t rkey = p.drop_thresh ? rng_row_key(p.seed, p.stream, (uint32_t)(((size_t)b * p.H + h) * p.Tq + q)) : 0u;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int key = k0 + 16 * ks + l15;
+                    const bool valid = qok && key < klen && (!p.causal || key <= q);
+                    const float pv = valid ? exp2f(s[qs][ks][r] * sc - l2) : 0.f;
+                    float pd = pv, dpe = dp[qs][ks][r];
+                    if (p.drop_thresh) {
+                        const bool keep = rng_keep(rkey, (uint32_t)key, p.drop_thresh);
+                        pd = keep ? pv * p.drop_scale : 0.f;
+                        dpe = keep ? dpe * p.drop_scale : 0.f;
+                    }
+                    s[qs][ks][r] = pd;                       // dropped probabilities (B operand of dV)
+                    dp[qs][ks][r] = pv * (dpe - de);         // dS (B operand of dK)
+                }
+            }
+        // ---- dV^T += dO^T . Pd ;  dK^T += Q^T . dS  (sum over the 32 queries of the tile) ------------------
+        bf16x8_t pf[2][PARTS], sf[2][PARTS];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t hi, lo;
+            pack_acc<NSPLIT>(s[0][ks], s[1][ks], hi, lo);
+            pf[ks][0] = hi; if (PARTS == 2) pf[ks][PARTS - 1] = lo;
+            pack_acc<NSPLIT>(dp[0][ks], dp[1][ks], hi, lo);
+            sf[ks][0] = hi; if (PARTS == 2) sf[ks][PARTS - 1] = lo;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8_t doh = tr_frag(sD[0], 0, 16 * dt, l15, g);
+            const bf16x8_t dol = (PARTS == 2) ? tr_frag(sD[PARTS - 1], 0, 16 * dt, l15, g) : doh;
+            const bf16x8_t qh = tr_frag(sQ[0], 0, 16 * dt, l15, g);
+            const bf16x8_t ql = (PARTS == 2) ? tr_frag(sQ[PARTS - 1], 0, 16 * dt, l15, g) : qh;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                dv[dt][ks] = mma3<NSPLIT>(doh, dol, pf[ks][0], pf[ks][PARTS - 1], dv[dt][ks]);
+                dk[dt][ks] = mma3<NSPLIT>(qh, ql, sf[ks][0], sf[ks][PARTS - 1], dk[dt][ks]);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: lane holds dK^T[d = 16dt+4g+r][key = k0+16ks+l15] ---------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int key = k0 + 16 * ks + l15;
+        if (key >= p.Tk) continue;
+        float* dkp = p.dK + ((size_t)b * p.Tk + key) * p.lddk + h * HD + 4 * g;
+        float* dvp = p.dV + ((size_t)b * p.Tk + key) * p.lddv + h * HD + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            *reinterpret_cast<float4*>(dkp + 16 * dt) = make_float4(dk[dt][ks][0] * p.scale, dk[dt][ks][1] * p.scale, dk[dt][ks][2] * p.scale, dk[dt][ks][3] * p.scale);
+            *reinterpret_cast<float4*>(dvp + 16 * dt) = make_float4(dv[dt][ks][0], dv[dt][ks][1], dv[dt][ks][2], dv[dt][ks][3]);
+        }
+    }
+}
+
+// Delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]; one wave per (b,q) row of H*64 = 256 columns (H == 4) or generic H.
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dO, int lddo, const float* __restrict__ O, int ldo,
+                                                         float* __restrict__ delta, int rows, int Tq, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / Tq, q = row - b * Tq;
+    for (int h0 = 0; h0 < H; h0 += 4) {                   // 4 heads (256 columns) per pass, 16 lanes per head
+        const int h = h0 + (lane >> 4);
+        float s = 0.f;
+        if (h < H) {
+            const int c = h * HD + (lane & 15) * 4;
+            float4 a = *reinterpret_cast<const float4*>(dO + (size_t)row * lddo + c);
+            float4 o = *reinterpret_cast<const float4*>(O + (size_t)row * ldo + c);
+            s = (a.x * o.x + a.y * o.y) + (a.z * o.z + a.w * o.w);
+        }
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+        if (h < H && (lane & 15) == 0) delta[((size_t)b * H + h) * Tq + q] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+static int fill_common(AttnParams& p, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const int* lens_k,
+                       int B, int H, int Tq, int Tk, int head_dim, int causal, float scale, float drop_p, unsigned seed, unsigned stream_id) {
+    UNAST_REQUIRE(Q && K && V, "unast_attn: null Q/K/V");
+    UNAST_REQUIRE(head_dim == HD, "unast_attn: this build supports head_dim=%d only (got %d)", HD, head_dim);
+    UNAST_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "unast_attn: bad dims");
+    UNAST_REQUIRE(al16(Q) && al16(K) && al16(V) && (ldq & 3) == 0 && (ldk & 3) == 0 && (ldv & 3) == 0, "unast_attn: Q/K/V must be 16-byte aligned with ld%%4==0");
+    UNAST_REQUIRE(!causal || Tq == Tk, "unast_attn: causal masking requires Tq == Tk");
+    p.Q = Q; p.K = K; p.V = V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.lens_k = lens_k;
+    p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.causal = causal; p.scale = scale;
+    p.drop_thresh = drop_threshold(drop_p); p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.seed = seed; p.stream = stream_id;
+    p.O = nullptr; p.LSE = nullptr; p.dO = nullptr; p.Delta = nullptr; p.dK = nullptr; p.dV = nullptr; p.ldo = p.lddo = p.lddk = p.lddv = 0;
+    return UNAST_OK;
+}
+
+extern "C" int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                              float* LSE, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
+                              float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream) {
+    AttnParams p;
+    int rc = fill_common(p, Q, ldq, K, ldk, V, ldv, lens_k, B, H, Tq, Tk, head_dim, causal, scale, drop_p, seed, stream_id);
+    if (rc) return rc;
+    UNAST_REQUIRE(O && LSE && al16(O) && (ldo & 3) == 0, "unast_attn_fwd: bad output");
+    UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_attn_fwd: nsplit must be 1 or 3");
+    p.O = O; p.ldo = ldo; p.LSE = LSE;
+    dim3 grid((Tq + 127) / 128, H, B);
+    if (nsplit == 3) hipLaunchKernelGGL((attn_q_kernel<3, 0>), grid, dim3(256), 0, stream, p);
+    else             hipLaunchKernelGGL((attn_q_kernel<1, 0>), grid, dim3(256), 0, stream, p);
+    return unast_check_launch("unast_attn_fwd");
+}
+
+extern "C" int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                              const float* dO, int lddo, const float* LSE, float* delta_ws, float* dQ, int lddq, float* dK, int lddk,
+                              float* dV, int lddv, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
+                              float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream) {
+    AttnParams p;
+    int rc = fill_common(p, Q, ldq, K, ldk, V, ldv, lens_k, B, H, Tq, Tk, head_dim, causal, scale, drop_p, seed, stream_id);
+    if (rc) return rc;
+    UNAST_REQUIRE(O && dO && LSE && delta_ws && dQ && dK && dV, "unast_attn_bwd: null pointer");
+    UNAST_REQUIRE(al16(O) && al16(dO) && al16(dQ) && al16(dK) && al16(dV) && ((ldo | lddo | lddq | lddk | lddv) & 3) == 0,
+                  "unast_attn_bwd: operands must be 16-byte aligned with ld%%4==0");
+    UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_attn_bwd: nsplit must be 1 or 3");
+    const int rows = B * Tq;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, dO, lddo, O, ldo, delta_ws, rows, Tq, H);
+    p.dO = dO; p.lddo = lddo; p.LSE = const_cast<float*>(LSE); p.Delta = delta_ws;
+    p.O = dQ; p.ldo = lddq; p.dK = dK; p.dV = dV; p.lddk = lddk; p.lddv = lddv;
+    dim3 gq((Tq + 127) / 128, H, B), gk((Tk + 127) / 128, H, B);
+    if (nsplit == 3) {
+        hipLaunchKernelGGL((attn_q_kernel<3, 1>), gq, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_dkv_kernel<3>), gk, dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((attn_q_kernel<1, 1>), gq, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_dkv_kernel<1>), gk, dim3(256), 0, stream, p);
+    }
+    return unast_check_launch("unast_attn_bwd");
+}

@@ -1,0 +1,216 @@
+// Fused output-head losses, forward (scalar) and backward (dlogits in one pass), for gfx950.
+//   speech_loss   src/train.py:100-103,113-122  masked MSE (pre + post) + BCE-with-logits(pos_weight) on stop tokens
+//   text_loss     src/train.py:105-111          weighted cross-entropy, ignore_index = PAD
+//   disc loss     src/train.py:147-164,296-335  BCE-with-logits against label-smoothed (0.9/0.1) targets
+// Reductions are accumulated in double (wave shuffle -> one atomic per wave); the final scalar is fp32.
+#include "common.h"
+
+// ws layout (doubles): [0] sum mask*(gold-pre)^2  [1] sum mask*(gold-post)^2  [2] sum bce(stop)
+__global__ __launch_bounds__(256) void speech_loss_partial_kernel(const float* __restrict__ gold, const float* __restrict__ head, int ldh,
+                                                                  const float* __restrict__ post, const int* __restrict__ lens, int B, int T, int M,
+                                                                  float eos_weight, double* __restrict__ ws) {
+    const int rows = B * T;
+    const int mq = M >> 2;
+    const size_t total = (size_t)rows * mq;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / mq), c = (int)(i - (size_t)r * mq) * 4;
+        const int b = r / T, t = r - b * T;
+        const int len = lens[b];
+        if (t < len) {
+            float4 g = *reinterpret_cast<const float4*>(gold + (size_t)r * M + c);
+            float4 p = *reinterpret_cast<const float4*>(head + (size_t)r * ldh + c);
+            float4 q = *reinterpret_cast<const float4*>(post + (size_t)r * M + c);
+            float d;
+            d = g.x - p.x; a0 += d * d; d = g.y - p.y; a0 += d * d; d = g.z - p.z; a0 += d * d; d = g.w - p.w; a0 += d * d;
+            d = g.x - q.x; a1 += d * d; d = g.y - q.y; a1 += d * d; d = g.z - q.z; a1 += d * d; d = g.w - q.w; a1 += d * d;
+        }
+        if (c == 0) {
+            const float x = head[(size_t)r * ldh + M];
+            const float y = (t == len - 1) ? 1.f : 0.f;
+            const float lw = 1.f + (eos_weight - 1.f) * y;
+            a2 += (1.f - y) * x + lw * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f));
+        }
+    }
+    double d0 = wave_sum_d((double)a0), d1 = wave_sum_d((double)a1), d2 = wave_sum_d((double)a2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(ws + 0, d0); atomicAdd(ws + 1, d1); atomicAdd(ws + 2, d2); }
+}
+
+__global__ void speech_loss_final_kernel(const double* __restrict__ ws, const int* __restrict__ lens, int B, int T, int M, float* __restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double sl = 0.0;
+        for (int b = 0; b < B; ++b) sl += (double)lens[b];
+        const double denom = sl * (double)M;
+        loss[0] = (float)(ws[0] / denom + ws[1] / denom + ws[2] / ((double)B * T));
+    }
+}
+
+// d_head [rows, ldh]: cols [0,M) = g*2*(pre-gold)*mask/denom, col M = g*dBCE/(B*T), remaining pad cols = 0.
+// d_post [rows, M]   = g*2*(post-gold)*mask/denom.   g = *gscale (device scalar: upstream dL/dloss).
+__global__ __launch_bounds__(256) void speech_loss_bwd_kernel(const float* __restrict__ gold, const float* __restrict__ head, int ldh,
+                                                              const float* __restrict__ post, const int* __restrict__ lens, int B, int T, int M,
+                                                              float eos_weight, const float* __restrict__ gscale, float* __restrict__ d_head,
+                                                              float* __restrict__ d_post) {
+    __shared__ float s_denom;
+    if (threadIdx.x == 0) {
+        double sl = 0.0;
+        for (int b = 0; b < B; ++b) sl += (double)lens[b];
+        s_denom = (float)(sl * (double)M);
+    }
+    __syncthreads();
+    const float g = gscale[0];
+    const float km = 2.f * g / s_denom;
+    const float ks = g / (float)(B * T);
+    const int rows = B * T;
+    const int hq = ldh >> 2;
+    const size_t total = (size_t)rows * hq;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / hq), c = (int)(i - (size_t)r * hq) * 4;
+        const int b = r / T, t = r - b * T;
+        const int len = lens[b];
+        float4 o = make_float4(0, 0, 0, 0);
+        if (c < M) {
+            float4 op = make_float4(0, 0, 0, 0);
+            if (t < len) {
+                float4 gd = *reinterpret_cast<const float4*>(gold + (size_t)r * M + c);
+                float4 p = *reinterpret_cast<const float4*>(head + (size_t)r * ldh + c);
+                float4 q = *reinterpret_cast<const float4*>(post + (size_t)r * M + c);
+                o = make_float4(km * (p.x - gd.x), km * (p.y - gd.y), km * (p.z - gd.z), km * (p.w - gd.w));
+                op = make_float4(km * (q.x - gd.x), km * (q.y - gd.y), km * (q.z - gd.z), km * (q.w - gd.w));
+            }
+            *reinterpret_cast<float4*>(d_post + (size_t)r * M + c) = op;
+        } else if (c == M) {
+            const float x = head[(size_t)r * ldh + M];
+            const float y = (t == len - 1) ? 1.f : 0.f;
+            const float lw = 1.f + (eos_weight - 1.f) * y;
+            const float sig = 1.f / (1.f + expf(-x));
+            o.x = ks * ((1.f - y) - lw * (1.f - sig));
+        }
+        *reinterpret_cast<float4*>(d_head + (size_t)r * ldh + c) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Text loss: one thread per token (V = 46 logits).  ws doubles: [0] sum w*nll, [1] sum w.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void text_loss_partial_kernel(const float* __restrict__ logits, int ldl, const int64_t* __restrict__ gold, int rows, int V,
+                                                                int eos_idx, float eos_weight, int pad_idx, double* __restrict__ ws) {
+    float a = 0.f, w = 0.f;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+        const int y = (int)gold[r];
+        if (y == pad_idx) continue;
+        const float* lr = logits + (size_t)r * ldl;
+        float mx = lr[0];
+        for (int v = 1; v < V; ++v) mx = fmaxf(mx, lr[v]);
+        float se = 0.f;
+        for (int v = 0; v < V; ++v) se += expf(lr[v] - mx);
+        const float wy = (y == eos_idx) ? eos_weight : 1.f;
+        a += wy * (logf(se) + mx - lr[y]);
+        w += wy;
+    }
+    double da = wave_sum_d((double)a), dw = wave_sum_d((double)w);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(ws + 0, da); atomicAdd(ws + 1, dw); }
+}
+
+__global__ void text_loss_final_kernel(const double* __restrict__ ws, float* __restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) loss[0] = (float)(ws[0] / ws[1]);
+}
+
+__global__ __launch_bounds__(256) void text_loss_bwd_kernel(const float* __restrict__ logits, int ldl, const int64_t* __restrict__ gold, int rows, int V,
+                                                            int eos_idx, float eos_weight, int pad_idx, const double* __restrict__ ws,
+                                                            const float* __restrict__ gscale, float* __restrict__ dlogits) {
+    const float k = gscale[0] / (float)ws[1];
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+        const int y = (int)gold[r];
+        float* dr = dlogits + (size_t)r * ldl;
+        if (y == pad_idx) {
+            for (int v = 0; v < ldl; ++v) dr[v] = 0.f;
+            continue;
+        }
+        const float* lr = logits + (size_t)r * ldl;
+        float mx = lr[0];
+        for (int v = 1; v < V; ++v) mx = fmaxf(mx, lr[v]);
+        float se = 0.f;
+        for (int v = 0; v < V; ++v) se += expf(lr[v] - mx);
+        const float wy = ((y == eos_idx) ? eos_weight : 1.f) * k;
+        const float inv = 1.f / se;
+        for (int v = 0; v < V; ++v) dr[v] = wy * (expf(lr[v] - mx) * inv - (v == y ? 1.f : 0.f));
+        for (int v = V; v < ldl; ++v) dr[v] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Discriminator BCE (single block; n = 2B is tiny).  target_i = (perm[i] < B ? 0.9 : 0.1), flipped for the generator.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void disc_bce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ perm, int n, int B, int flip,
+                                                       float smoothing, const float* __restrict__ gscale, float* __restrict__ loss,
+                                                       float* __restrict__ dlogits) {
+    __shared__ float red[4];
+    float a = 0.f;
+    const float g = gscale ? gscale[0] : 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float y = (perm[i] < B) ? (1.f - smoothing) : 1.f - (1.f - smoothing);
+        if (flip) y = 1.f - y;
+        const float x = logits[i];
+        a += (1.f - y) * x + log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f);
+        if (dlogits) dlogits[i] = g * (1.f / (1.f + expf(-x)) - y) / (float)n;
+    }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+static int ls_grid(size_t work, int cap = 1024) {
+    size_t b = (work + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > (size_t)cap) b = cap;
+    return (int)b;
+}
+
+extern "C" int unast_speech_loss_fwd(const float* gold, const float* head, int ldh, const float* post, const int* lens, int B, int T, int M,
+                                     float eos_weight, double* ws /* 3 doubles */, float* loss, hipStream_t stream) {
+    UNAST_REQUIRE(gold && head && post && lens && ws && loss, "unast_speech_loss_fwd: null pointer");
+    UNAST_REQUIRE(B > 0 && T > 0 && (M & 3) == 0 && ldh > M && (ldh & 3) == 0, "unast_speech_loss_fwd: need M%%4==0 and ldh>M, ldh%%4==0");
+    hipMemsetAsync(ws, 0, 3 * sizeof(double), stream);
+    hipLaunchKernelGGL(speech_loss_partial_kernel, dim3(ls_grid((size_t)B * T * (M / 4))), dim3(256), 0, stream, gold, head, ldh, post, lens, B, T, M,
+                       eos_weight, ws);
+    hipLaunchKernelGGL(speech_loss_final_kernel, dim3(1), dim3(64), 0, stream, ws, lens, B, T, M, loss);
+    return unast_check_launch("unast_speech_loss_fwd");
+}
+
+extern "C" int unast_speech_loss_bwd(const float* gold, const float* head, int ldh, const float* post, const int* lens, int B, int T, int M,
+                                     float eos_weight, const float* gscale, float* d_head, float* d_post, hipStream_t stream) {
+    UNAST_REQUIRE(gold && head && post && lens && gscale && d_head && d_post, "unast_speech_loss_bwd: null pointer");
+    UNAST_REQUIRE(B > 0 && T > 0 && (M & 3) == 0 && ldh > M && (ldh & 3) == 0, "unast_speech_loss_bwd: need M%%4==0 and ldh>M, ldh%%4==0");
+    hipLaunchKernelGGL(speech_loss_bwd_kernel, dim3(ls_grid((size_t)B * T * (ldh / 4))), dim3(256), 0, stream, gold, head, ldh, post, lens, B, T, M,
+                       eos_weight, gscale, d_head, d_post);
+    return unast_check_launch("unast_speech_loss_bwd");
+}
+
+extern "C" int unast_text_loss_fwd(const float* logits, int ldl, const int64_t* gold, int rows, int V, float eos_weight,
+                                   double* ws /* 2 doubles, kept for bwd */, float* loss, hipStream_t stream) {
+    UNAST_REQUIRE(logits && gold && ws && loss && rows > 0 && V > 0 && ldl >= V, "unast_text_loss_fwd: bad arguments");
+    hipMemsetAsync(ws, 0, 2 * sizeof(double), stream);
+    hipLaunchKernelGGL(text_loss_partial_kernel, dim3(ls_grid(rows)), dim3(256), 0, stream, logits, ldl, gold, rows, V, 2, eos_weight, 0, ws);
+    hipLaunchKernelGGL(text_loss_final_kernel, dim3(1), dim3(64), 0, stream, ws, loss);
+    return unast_check_launch("unast_text_loss_fwd");
+}
+
+extern "C" int unast_text_loss_bwd(const float* logits, int ldl, const int64_t* gold, int rows, int V, float eos_weight, const double* ws,
+                                   const float* gscale, float* dlogits, hipStream_t stream) {
+    UNAST_REQUIRE(logits && gold && ws && gscale && dlogits && rows > 0 && V > 0 && ldl >= V, "unast_text_loss_bwd: bad arguments");
+    hipLaunchKernelGGL(text_loss_bwd_kernel, dim3(ls_grid(rows)), dim3(256), 0, stream, logits, ldl, gold, rows, V, 2, eos_weight, 0, ws, gscale, dlogits);
+    return unast_check_launch("unast_text_loss_bwd");
+}
+
+extern "C" int unast_disc_bce(const float* logits, const int64_t* perm, int n, int B, int flip, float smoothing, const float* gscale,
+                              float* loss, float* dlogits, hipStream_t stream) {
+    UNAST_REQUIRE(logits && perm && n > 0, "unast_disc_bce: bad arguments");
+    UNAST_REQUIRE((dlogits == nullptr) || gscale, "unast_disc_bce: dlogits requires gscale");
+    hipLaunchKernelGGL(disc_bce_kernel, dim3(1), dim3(256), 0, stream, logits, perm, n, B, flip, smoothing, gscale, loss, dlogits);
+    return unast_check_launch("unast_disc_bce");
+}

@@ -1,0 +1,379 @@
+// LayerNorm (post-LN transformer blocks) and train-mode BatchNorm1d (conv stacks) for gfx950.
+// All kernels are HBM-bound: one pass over each operand with 16-byte loads per lane, statistics in registers,
+// cross-lane reductions with wave shuffles.  Reference semantics: torch.nn.LayerNorm(eps=1e-5) inside
+// torch.nn.TransformerEncoderLayer/DecoderLayer (src/module.py:273-274, 286-287) and nn.BatchNorm1d in training
+// mode over all B*T positions incl. padding (src/module.py:145-147, 208-210).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row, C <= 1024, C % 4 == 0.  y = (z-mean)*rstd*gamma + beta
+// ------------------------------------------------------------------------------------------------------------
+#define LN_MAXV 4
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ z, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* zr = z + (size_t)row * C;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        int c = (lane + 64 * i) * 4;
+        if (c < C) {
+            v[i] = *reinterpret_cast<const float4*>(zr + c);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        int c = (lane + 64 * i) * 4;
+        if (c < C) {
+            float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    float* yr = y + (size_t)row * C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        int c = (lane + 64 * i) * 4;
+        if (c < C) {
+            float4 g = *reinterpret_cast<const float4*>(gamma + c);
+            float4 b = *reinterpret_cast<const float4*>(beta + c);
+            float4 o;
+            o.x = (v[i].x - mu) * rs * g.x + b.x;
+            o.y = (v[i].y - mu) * rs * g.y + b.y;
+            o.z = (v[i].z - mu) * rs * g.z + b.z;
+            o.w = (v[i].w - mu) * rs * g.w + b.w;
+            *reinterpret_cast<float4*>(yr + c) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  dz = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma;  dgamma += sum dy*xhat,
+// dbeta += sum dy (block partials, then fp32 atomics into the gradient buffer).  Optional second output
+// dz_drop = dz * dropout-mask(seed,stream,row,col) / (1-p): the gradient of the sub-layer output that was
+// dropped before the residual add in the forward pass.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dz,
+                                                            float* __restrict__ dz_drop, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int rows, int C, int rows_per_block,
+                                                            uint32_t drop_thresh, float drop_scale, uint32_t seed, uint32_t stream) {
+    __shared__ float red[2][4][LN_MAXV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 ag[LN_MAXV], ab[LN_MAXV], gm[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        ag[i] = make_float4(0, 0, 0, 0);
+        ab[i] = make_float4(0, 0, 0, 0);
+        int c = (lane + 64 * i) * 4;
+        gm[i] = (c < C) ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0, 0, 0, 0);
+    }
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[LN_MAXV], g[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            int c = (lane + 64 * i) * 4;
+            if (c < C) {
+                float4 d = *reinterpret_cast<const float4*>(dy + (size_t)row * C + c);
+                float4 zz = *reinterpret_cast<const float4*>(z + (size_t)row * C + c);
+                xh[i] = make_float4((zz.x - mu) * rs, (zz.y - mu) * rs, (zz.z - mu) * rs, (zz.w - mu) * rs);
+                g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
+        uint32_t rkey = drop_thresh ? rng_row_key(seed, stream, (uint32_t)row) : 0u;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            int c = (lane + 64 * i) * 4;
+            if (c < C) {
+                float4 o;
+                o.x = rs * (g[i].x - c1 - xh[i].x * c2);
+                o.y = rs * (g[i].y - c1 - xh[i].y * c2);
+                o.z = rs * (g[i].z - c1 - xh[i].z * c2);
+                o.w = rs * (g[i].w - c1 - xh[i].w * c2);
+                *reinterpret_cast<float4*>(dz + (size_t)row * C + c) = o;
+                if (dz_drop) {
+                    float4 od;
+                    od.x = rng_keep(rkey, c + 0, drop_thresh) ? o.x * drop_scale : 0.f;
+                    od.y = rng_keep(rkey, c + 1, drop_thresh) ? o.y * drop_scale : 0.f;
+                    od.z = rng_keep(rkey, c + 2, drop_thresh) ? o.z * drop_scale : 0.f;
+                    od.w = rng_keep(rkey, c + 3, drop_thresh) ? o.w * drop_scale : 0.f;
+                    *reinterpret_cast<float4*>(dz_drop + (size_t)row * C + c) = od;
+                }
+            }
+        }
+    }
+    if (!dgamma) return;
+    // block reduction of the column partials (4 waves) then one atomic per column per block
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        int c = (lane + 64 * i) * 4;
+        if (c < C) {
+            *reinterpret_cast<float4*>(&red[0][wave][c]) = ag[i];
+            *reinterpret_cast<float4*>(&red[1][wave][c]) = ab[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float sg = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        float sb = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+        atomicAdd(dgamma + c, sg);
+        atomicAdd(dbeta + c, sb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Column sums over rows: s1[c] += sum_r x[r,c] ; s2[c] += sum_r x[r,c]^2 (s2 optional).
+// Used for BatchNorm batch statistics (double accumulators) and bias gradients (float accumulators).
+// Thread (tx, ty): tx = column quad, ty = row lane; per-thread fp32 partials over <= rows_per_block/nry rows.
+// ------------------------------------------------------------------------------------------------------------
+template <typename ACC>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, int rows, int C, int rows_per_block,
+                                                     ACC* __restrict__ s1, ACC* __restrict__ s2) {
+    __shared__ float red[2][256][4];
+    const int cq = C >> 2;
+    const int nry = 256 / cq;
+    const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
+    float4 a = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    if (ty < nry) {
+        for (int r = r0 + ty; r < r1; r += nry) {
+            float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + tx * 4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+        }
+    }
+    *reinterpret_cast<float4*>(red[0][threadIdx.x]) = a;
+    *reinterpret_cast<float4*>(red[1][threadIdx.x]) = q;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int qd = c >> 2, e = c & 3;
+        float sa = 0.f, sq = 0.f;
+        for (int yy = 0; yy < nry; ++yy) { sa += red[0][yy * cq + qd][e]; sq += red[1][yy * cq + qd][e]; }
+        atomicAdd(s1 + c, (ACC)sa);
+        if (s2) atomicAdd(s2 + c, (ACC)sq);
+    }
+}
+
+// BatchNorm statistics finalize: mean/rstd (biased variance) + running-stat update (momentum, unbiased variance).
+__global__ void bn_finalize_kernel(const double* __restrict__ s1, const double* __restrict__ s2, int C, double n, float eps,
+                                   float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = s1[c] / n;
+    double var = s2[c] / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+__device__ __forceinline__ float act_fwd(float x, int act) { return act == 1 ? fmaxf(x, 0.f) : (act == 2 ? tanhf(x) : x); }
+
+// y = dropout(act((x-mean)*rstd*gamma + beta));  act: 0 none, 1 relu, 2 tanh.  rows x C, float4 per thread.
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y, int rows, int C,
+                                                           int act, uint32_t drop_thresh, float drop_scale, uint32_t seed, uint32_t stream) {
+    const int cq = C >> 2;
+    const size_t total = (size_t)rows * cq;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / cq), c = (int)(i - (size_t)r * cq) * 4;
+        float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + c);
+        float4 m = *reinterpret_cast<const float4*>(mean + c), s = *reinterpret_cast<const float4*>(rstd + c);
+        float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+        float o[4] = {(v.x - m.x) * s.x * g.x + b.x, (v.y - m.y) * s.y * g.y + b.y, (v.z - m.z) * s.z * g.z + b.z,
+                      (v.w - m.w) * s.w * g.w + b.w};
+        uint32_t rkey = drop_thresh ? rng_row_key(seed, stream, (uint32_t)r) : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = act_fwd(o[e], act);
+            if (drop_thresh) a = rng_keep(rkey, c + e, drop_thresh) ? a * drop_scale : 0.f;
+            o[e] = a;
+        }
+        *reinterpret_cast<float4*>(y + (size_t)r * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// BatchNorm backward, pass 1: dpre = dy * dropmask/(1-p) * act'(pre) written IN PLACE over dy, and the column sums
+// S1 = sum dpre (= dbeta), S2 = sum dpre*xhat (= dgamma) accumulated in double.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int rows, int C, int rows_per_block, int act, uint32_t drop_thresh,
+                                                            float drop_scale, uint32_t seed, uint32_t stream,
+                                                            double* __restrict__ S1, double* __restrict__ S2) {
+    __shared__ float red[2][256][4];
+    const int cq = C >> 2;
+    const int nry = 256 / cq;
+    const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
+    const int c = tx * 4;
+    float a[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    if (ty < nry) {
+        float4 m = *reinterpret_cast<const float4*>(mean + c), s = *reinterpret_cast<const float4*>(rstd + c);
+        float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+        const float mm[4] = {m.x, m.y, m.z, m.w}, ss[4] = {s.x, s.y, s.z, s.w}, gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+        for (int r = r0 + ty; r < r1; r += nry) {
+            float4 d4 = *reinterpret_cast<const float4*>(dy + (size_t)r * C + c);
+            float4 x4 = *reinterpret_cast<const float4*>(x + (size_t)r * C + c);
+            float d[4] = {d4.x, d4.y, d4.z, d4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+            uint32_t rkey = drop_thresh ? rng_row_key(seed, stream, (uint32_t)r) : 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xv[e] - mm[e]) * ss[e];
+                const float pre = xh * gg[e] + bb[e];
+                float dd = d[e];
+                if (drop_thresh) dd = rng_keep(rkey, c + e, drop_thresh) ? dd * drop_scale : 0.f;
+                if (act == 1) dd = pre > 0.f ? dd : 0.f;
+                else if (act == 2) { const float th = tanhf(pre); dd *= (1.f - th * th); }
+                d[e] = dd;
+                a[e] += dd;
+                q[e] += dd * xh;
+            }
+            *reinterpret_cast<float4*>(dy + (size_t)r * C + c) = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    }
+    *reinterpret_cast<float4*>(red[0][threadIdx.x]) = make_float4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<float4*>(red[1][threadIdx.x]) = make_float4(q[0], q[1], q[2], q[3]);
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < C; cc += 256) {
+        const int qd = cc >> 2, e = cc & 3;
+        float sa = 0.f, sq = 0.f;
+        for (int yy = 0; yy < nry; ++yy) { sa += red[0][yy * cq + qd][e]; sq += red[1][yy * cq + qd][e]; }
+        atomicAdd(S1 + cc, (double)sa);
+        atomicAdd(S2 + cc, (double)sq);
+    }
+}
+
+// BatchNorm backward, pass 2: dx = gamma*rstd*(dpre - S1/n - xhat*S2/n); also dgamma += S2, dbeta += S1 (block 0).
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dpre, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const double* __restrict__ S1,
+                                                           const double* __restrict__ S2, float* __restrict__ dx, int rows, int C,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int cq = C >> 2;
+    const size_t total = (size_t)rows * cq;
+    const float invn = 1.f / (float)rows;
+    if (blockIdx.x == 0 && dgamma) {
+        for (int c = threadIdx.x; c < C; c += 256) { dgamma[c] += (float)S2[c]; dbeta[c] += (float)S1[c]; }
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / cq), c = (int)(i - (size_t)r * cq) * 4;
+        float4 d = *reinterpret_cast<const float4*>(dpre + (size_t)r * C + c);
+        float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * C + c);
+        float4 m = *reinterpret_cast<const float4*>(mean + c), s = *reinterpret_cast<const float4*>(rstd + c);
+        float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        const float s1[4] = {(float)S1[c] * invn, (float)S1[c + 1] * invn, (float)S1[c + 2] * invn, (float)S1[c + 3] * invn};
+        const float s2[4] = {(float)S2[c] * invn, (float)S2[c + 1] * invn, (float)S2[c + 2] * invn, (float)S2[c + 3] * invn};
+        float4 o;
+        o.x = g.x * s.x * (d.x - s1[0] - (xv.x - m.x) * s.x * s2[0]);
+        o.y = g.y * s.y * (d.y - s1[1] - (xv.y - m.y) * s.y * s2[1]);
+        o.z = g.z * s.z * (d.z - s1[2] - (xv.z - m.z) * s.z * s2[2]);
+        o.w = g.w * s.w * (d.w - s1[3] - (xv.w - m.w) * s.w * s2[3]);
+        *reinterpret_cast<float4*>(dx + (size_t)r * C + c) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+static int grid_for(size_t work, int per_block, int cap = 2048) {
+    size_t b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > (size_t)cap) b = cap;
+    return (int)b;
+}
+
+extern "C" int unast_layernorm_fwd(const float* z, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                   int rows, int C, float eps, hipStream_t stream) {
+    UNAST_REQUIRE(z && gamma && beta && y && mean && rstd, "unast_layernorm_fwd: null pointer");
+    UNAST_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && C <= 1024, "unast_layernorm_fwd: need C%%4==0, C<=1024 (C=%d)", C);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, z, gamma, beta, y, mean, rstd, rows, C, eps);
+    return unast_check_launch("unast_layernorm_fwd");
+}
+
+extern "C" int unast_layernorm_bwd(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd,
+                                   float* dz, float* dz_drop, float* dgamma, float* dbeta, int rows, int C,
+                                   float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream) {
+    UNAST_REQUIRE(dy && z && gamma && mean && rstd && dz, "unast_layernorm_bwd: null pointer");
+    UNAST_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "unast_layernorm_bwd: dgamma/dbeta must both be given or both null");
+    UNAST_REQUIRE(rows > 0 && (C & 3) == 0 && C <= 1024, "unast_layernorm_bwd: need C%%4==0, C<=1024 (C=%d)", C);
+    int blocks = grid_for(rows, 32, 1024);
+    int rpb = (rows + blocks - 1) / blocks;
+    blocks = (rows + rpb - 1) / rpb;
+    uint32_t th = dz_drop ? drop_threshold(drop_p) : 0u;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, z, gamma, mean, rstd, dz,
+                       (th ? dz_drop : (float*)nullptr), dgamma, dbeta, rows, C, rpb, th, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, stream_id);
+    return unast_check_launch("unast_layernorm_bwd");
+}
+
+static int colsum_geometry(int rows, int C, int* blocks, int* rpb) {
+    if ((C & 3) != 0 || C > 1024 || C <= 0) return -1;
+    int b = grid_for(rows, 64, 1024);
+    *rpb = (rows + b - 1) / b;
+    *blocks = (rows + *rpb - 1) / *rpb;
+    return 0;
+}
+
+extern "C" int unast_colsum_f32(const float* x, int ldx, int rows, int C, float* sum, hipStream_t stream) {
+    UNAST_REQUIRE(x && sum, "unast_colsum_f32: null pointer");
+    int blocks, rpb;
+    UNAST_REQUIRE(colsum_geometry(rows, C, &blocks, &rpb) == 0 && (ldx & 3) == 0, "unast_colsum_f32: need C%%4==0, C<=1024, ldx%%4==0");
+    hipLaunchKernelGGL((colsum_kernel<float>), dim3(blocks), dim3(256), 0, stream, x, ldx, rows, C, rpb, sum, (float*)nullptr);
+    return unast_check_launch("unast_colsum_f32");
+}
+
+extern "C" int unast_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                            float* running_mean, float* running_var, double* ws /* 2*C doubles */, int rows, int C,
+                            float eps, float momentum, int act, float drop_p, unsigned int seed, unsigned int stream_id,
+                            hipStream_t stream) {
+    UNAST_REQUIRE(x && gamma && beta && y && mean && rstd && ws, "unast_bn_fwd: null pointer");
+    int blocks, rpb;
+    UNAST_REQUIRE(colsum_geometry(rows, C, &blocks, &rpb) == 0, "unast_bn_fwd: need C%%4==0, C<=1024 (C=%d)", C);
+    hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream);
+    hipLaunchKernelGGL((colsum_kernel<double>), dim3(blocks), dim3(256), 0, stream, x, C, rows, C, rpb, ws, ws + C);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, ws + C, C, (double)rows, eps, momentum,
+                       mean, rstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for((size_t)rows * (C / 4), 256)), dim3(256), 0, stream, x, mean, rstd, gamma, beta, y,
+                       rows, C, act, drop_threshold(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, stream_id);
+    return unast_check_launch("unast_bn_fwd");
+}
+
+extern "C" int unast_bn_bwd(float* dy_inout, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            float* dx, float* dgamma, float* dbeta, double* ws /* 2*C doubles */, int rows, int C, int act,
+                            float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream) {
+    UNAST_REQUIRE(dy_inout && x && mean && rstd && gamma && beta && dx && ws, "unast_bn_bwd: null pointer");
+    UNAST_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "unast_bn_bwd: dgamma/dbeta must both be given or both null");
+    int blocks, rpb;
+    UNAST_REQUIRE(colsum_geometry(rows, C, &blocks, &rpb) == 0, "unast_bn_bwd: need C%%4==0, C<=1024 (C=%d)", C);
+    hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, stream, dy_inout, x, mean, rstd, gamma, beta, rows, C, rpb, act,
+                       drop_threshold(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, stream_id, ws, ws + C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)rows * (C / 4), 256)), dim3(256), 0, stream, dy_inout, x, mean, rstd, gamma,
+                       ws, ws + C, dx, rows, C, dgamma, dbeta);
+    return unast_check_launch("unast_bn_bwd");
+}

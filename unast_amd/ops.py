@@ -94,3 +94,156 @@ def conv_wgrad(dy3d, x3d, dWp, pad_left):
     gemm(OP_RC, OP_RC_CONV_WGRAD, dy3d, dy3d.stride(1), x3d, x3d.stride(1), dWp, 5 * Cin, Cout, 5 * Cin, B * T,
          conv=(T, 0, Cin, pad_left), beta=1, splitk=sk)
     return dWp
+
+
+# ---- attention ---------------------------------------------------------------------------------------------
+def attn_fwd(Q, K, V, O, LSE, lens_k, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, stream_id=0, nsplit=None):
+    """Q/K/V/O are 2-D views [B*T, >=H*64] (column slices of projection outputs are fine)."""
+    check(lib().unast_attn_fwd(nsplit or config.NSPLIT, _p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0),
+                               _p(LSE), _p(lens_k), B, H, Tq, Tk, 64, int(causal), 0.125, drop_p, seed & 0xFFFFFFFF, stream_id,
+                               _stream()), "unast_attn_fwd")
+
+
+def attn_bwd(Q, K, V, O, dO, LSE, delta_ws, dQ, dK, dV, lens_k, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, stream_id=0, nsplit=None):
+    check(lib().unast_attn_bwd(nsplit or config.NSPLIT, _p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0),
+                               _p(dO), dO.stride(0), _p(LSE), _p(delta_ws), _p(dQ), dQ.stride(0), _p(dK), dK.stride(0), _p(dV),
+                               dV.stride(0), _p(lens_k), B, H, Tq, Tk, 64, int(causal), 0.125, drop_p, seed & 0xFFFFFFFF, stream_id,
+                               _stream()), "unast_attn_bwd")
+
+
+# ---- normalisation -----------------------------------------------------------------------------------------
+def layernorm_fwd(z, gamma, beta, y, mean, rstd, eps=1e-5):
+    rows, C = z.shape
+    check(lib().unast_layernorm_fwd(_p(z), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, C, eps, _stream()), "unast_layernorm_fwd")
+
+
+def layernorm_bwd(dy, z, gamma, mean, rstd, dz, dz_drop=None, dgamma=None, dbeta=None, drop_p=0.0, seed=0, stream_id=0):
+    rows, C = z.shape
+    check(lib().unast_layernorm_bwd(_p(dy), _p(z), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dz_drop), _p(dgamma), _p(dbeta), rows, C,
+                                    drop_p, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_layernorm_bwd")
+
+
+def colsum(x2d, out):
+    rows, C = x2d.shape
+    check(lib().unast_colsum_f32(_p(x2d), x2d.stride(0), rows, C, _p(out), _stream()), "unast_colsum_f32")
+
+
+def bn_fwd(x2d, gamma, beta, y, mean, rstd, running_mean, running_var, ws, act, drop_p=0.0, seed=0, stream_id=0, eps=1e-5, momentum=0.1):
+    rows, C = x2d.shape
+    check(lib().unast_bn_fwd(_p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(running_mean), _p(running_var), _p(ws), rows, C,
+                             eps, momentum, act, drop_p, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_bn_fwd")
+
+
+def bn_bwd(dy_inout, x2d, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, act, drop_p=0.0, seed=0, stream_id=0):
+    rows, C = x2d.shape
+    check(lib().unast_bn_bwd(_p(dy_inout), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta), _p(ws), rows, C,
+                             act, drop_p, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_bn_bwd")
+
+
+# ---- embedding / positional encoding / masks ---------------------------------------------------------------
+def embed_fwd(ids, E, out, T, shift_sos=-1, drop_p=0.0, seed=0, stream_id=0, noise_p=0.0, noise_stream=0):
+    rows = ids.numel()
+    check(lib().unast_embed_fwd(_p(ids), _p(E), _p(out), rows, T, E.shape[1], shift_sos, drop_p, seed & 0xFFFFFFFF, stream_id, noise_p,
+                                noise_stream, _stream()), "unast_embed_fwd")
+
+
+def embed_bwd(ids, dout, dE, T, shift_sos=-1, drop_p=0.0, seed=0, stream_id=0, noise_p=0.0, noise_stream=0, padding_idx=0):
+    rows = ids.numel()
+    check(lib().unast_embed_bwd(_p(ids), _p(dout), _p(dE), rows, T, dE.shape[1], dE.shape[0], shift_sos, padding_idx, drop_p,
+                                seed & 0xFFFFFFFF, stream_id, noise_p, noise_stream, _stream()), "unast_embed_bwd")
+
+
+def posenc_fwd(x2d, pe, y, T, scale, drop_p=0.0, seed=0, stream_id=0):
+    rows, D = x2d.shape
+    check(lib().unast_posenc_fwd(_p(x2d), _p(pe), _p(y), rows, T, D, scale, drop_p, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_posenc_fwd")
+
+
+def posenc_bwd(dy, gate, dx, scale, drop_p=0.0, seed=0, stream_id=0):
+    rows, D = dy.shape
+    check(lib().unast_posenc_bwd(_p(dy), _p(gate), _p(dx), rows, D, scale, drop_p, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_posenc_bwd")
+
+
+def rowmask(x2d, y, p, seed, stream_id):
+    rows, D = x2d.shape
+    check(lib().unast_rowmask(_p(x2d), _p(y), rows, D, p, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_rowmask")
+
+
+def add_inplace(a, b):
+    check(lib().unast_add_inplace(_p(a), _p(b), a.numel(), _stream()), "unast_add_inplace")
+
+
+def specaugment(mel, lens_i32, out, seed, stream_id, freq_mask=20, time_mask=100):
+    B, T, M = mel.shape
+    check(lib().unast_specaugment(_p(mel), _p(lens_i32), _p(out), B, T, M, freq_mask, time_mask, seed & 0xFFFFFFFF, stream_id, _stream()),
+          "unast_specaugment")
+
+
+def disc_gather(t_hid, s_hid, t_len, s_len, perm, out, out_len):
+    B, Tt, D = t_hid.shape
+    Ts = s_hid.shape[1]
+    check(lib().unast_disc_gather(_p(t_hid), _p(s_hid), _p(t_len), _p(s_len), _p(perm), _p(out), _p(out_len), B, Tt, Ts, D, _stream()),
+          "unast_disc_gather")
+
+
+def disc_scatter(dout, perm, dt_hid, ds_hid):
+    B, Tt, D = dt_hid.shape
+    Ts = ds_hid.shape[1]
+    check(lib().unast_disc_scatter(_p(dout), _p(perm), _p(dt_hid), _p(ds_hid), B, Tt, Ts, D, _stream()), "unast_disc_scatter")
+
+
+# ---- losses ------------------------------------------------------------------------------------------------
+def speech_loss_fwd(gold, head, post, lens_i32, eos_weight, ws, loss):
+    B, T, M = gold.shape
+    check(lib().unast_speech_loss_fwd(_p(gold), _p(head), head.stride(-2), _p(post), _p(lens_i32), B, T, M, eos_weight, _p(ws), _p(loss),
+                                      _stream()), "unast_speech_loss_fwd")
+
+
+def speech_loss_bwd(gold, head, post, lens_i32, eos_weight, gscale, d_head, d_post):
+    B, T, M = gold.shape
+    check(lib().unast_speech_loss_bwd(_p(gold), _p(head), head.stride(-2), _p(post), _p(lens_i32), B, T, M, eos_weight, _p(gscale),
+                                      _p(d_head), _p(d_post), _stream()), "unast_speech_loss_bwd")
+
+
+def text_loss_fwd(logits2d, gold, V, eos_weight, ws, loss):
+    check(lib().unast_text_loss_fwd(_p(logits2d), logits2d.stride(0), _p(gold), logits2d.shape[0], V, eos_weight, _p(ws), _p(loss),
+                                    _stream()), "unast_text_loss_fwd")
+
+
+def text_loss_bwd(logits2d, gold, V, eos_weight, ws, gscale, dlogits):
+    check(lib().unast_text_loss_bwd(_p(logits2d), logits2d.stride(0), _p(gold), logits2d.shape[0], V, eos_weight, _p(ws), _p(gscale),
+                                    _p(dlogits), _stream()), "unast_text_loss_bwd")
+
+
+def disc_bce(logits, perm, B, flip, loss=None, gscale=None, dlogits=None, smoothing=0.1):
+    check(lib().unast_disc_bce(_p(logits), _p(perm), logits.numel(), B, int(flip), smoothing, _p(gscale), _p(loss), _p(dlogits), _stream()),
+          "unast_disc_bce")
+
+
+# ---- LSTM discriminator ------------------------------------------------------------------------------------
+def lstm_fwd(xproj, whh, b_ih, b_hh, lens_i32, y, gates, cs, hprev, hfinal, ndir, whh_dir_stride, bias_dir_stride):
+    Bd, T = xproj.shape[0], xproj.shape[1]
+    check(lib().unast_lstm_fwd(_p(xproj), _p(whh), _p(b_ih), _p(b_hh), _p(lens_i32), _p(y), _p(gates), _p(cs), _p(hprev), _p(hfinal), Bd, T,
+                               ndir, 64, whh_dir_stride, bias_dir_stride, _stream()), "unast_lstm_fwd")
+
+
+def lstm_bwd(dy, dhfinal, whh, gates, cs, lens_i32, dgates, ndir, whh_dir_stride):
+    Bd, T = gates.shape[0], gates.shape[1]
+    check(lib().unast_lstm_bwd(_p(dy), _p(dhfinal), _p(whh), _p(gates), _p(cs), _p(lens_i32), _p(dgates), Bd, T, ndir, 64, whh_dir_stride,
+                               _stream()), "unast_lstm_bwd")
+
+
+def leaky_dropout(x, dy, out, slope, drop_p=0.0, seed=0, stream_id=0):
+    rows = x.shape[0]
+    D = x.numel() // rows
+    check(lib().unast_leaky_dropout(_p(x), _p(dy), _p(out), rows, D, slope, drop_p, seed & 0xFFFFFFFF, stream_id, _stream()),
+          "unast_leaky_dropout")
+
+
+# ---- optimizer ---------------------------------------------------------------------------------------------
+def sumsq(g, out):
+    check(lib().unast_sumsq(_p(g), g.numel(), _p(out), _stream()), "unast_sumsq")
+
+
+def adamw(p, g, m, v, sumsq_scalar, max_norm, lr, beta1, beta2, eps, wd, step):
+    check(lib().unast_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq_scalar), max_norm, lr, beta1, beta2, eps, wd, step, _stream()),
+          "unast_adamw")
