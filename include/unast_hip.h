@@ -100,6 +100,10 @@ int unast_rowmask(const float* x, float* y, int rows, int D, float p, unsigned i
                   hipStream_t stream);
 /* a += b : gradient accumulation for activations consumed by several ops (autograd's implicit add). */
 int unast_add_inplace(float* a, const float* b, int64_t n, hipStream_t stream);
+/* a *= alpha: averaging of all-reduced gradients across data-parallel ranks (new vs. the single-device reference). */
+int unast_scale_inplace(float* a, float alpha, int64_t n, hipStream_t stream);
+/* dst[:, :cols] += src[:, :cols] with independent row strides (autograd's add for padded gradient buffers). */
+int unast_add_strided(float* dst, int ldd, const float* src, int lds, int rows, int cols, hipStream_t stream);
 /* specaugment (src/utils.py:51-75), including its quirk of masking two TIME spans and no frequency columns. */
 int unast_specaugment(const float* mel, const int* lens, float* out, int B, int T, int M, int freq_mask, int time_mask,
                       unsigned int seed, unsigned int stream_id, hipStream_t stream);
@@ -120,10 +124,13 @@ int unast_text_loss_fwd(const float* logits, int ldl, const int64_t* gold, int r
                         double* ws, float* loss, hipStream_t stream);
 int unast_text_loss_bwd(const float* logits, int ldl, const int64_t* gold, int rows, int V, float eos_weight, const double* ws,
                         const float* gscale, float* dlogits, hipStream_t stream);
-/* discriminator_loss + discriminator_target (src/train.py:147-164, 319-320): BCE-with-logits against smoothed targets
- * derived from perm (rows < B are text); flip=1 for the generator phase.  loss/dlogits may be NULL. */
-int unast_disc_bce(const float* logits, const int64_t* perm, int n, int B, int flip, float smoothing, const float* gscale,
-                   float* loss, float* dlogits, hipStream_t stream);
+/* discriminator_target (src/train.py:150-164, 319-320): smoothed labels 0.9 (text rows: perm[i] < B) / 0.1 (speech),
+ * flipped (1-y) when flip=1 (generator phase). */
+int unast_disc_targets(const int64_t* perm, int n, int B, int flip, float smoothing, float* out, hipStream_t stream);
+/* discriminator_loss (src/train.py:147-148): mean BCE-with-logits; logits/dlogits may be strided (ldx/ldd elements).
+ * loss/dlogits may be NULL; dlogits is scaled by the device scalar *gscale. */
+int unast_bce_logits(const float* logits, int ldx, const float* targets, int n, const float* gscale, float* loss, float* dlogits,
+                     int ldd, hipStream_t stream);
 
 /* Recurrent part of nn.LSTM over packed sequences (src/module.py:306, 315-316), hidden 64, gate order i,f,g,o.
  * xproj [Bd,T,ndir*256] = X W_ih^T (no bias), y [Bd,T,ndir*64] and hprev pre-zeroed by the caller; gates/cs saved. */

@@ -227,9 +227,13 @@ def test_losses_match_oracle():
             tgt = 1 - tgt
         xr = x.clone().double().requires_grad_(True)
         ref = R.bce_logits_mean(xr, tgt.double()); (ref * 0.5).backward()
-        dlg = torch.empty(8, device=D)
-        ops.disc_bce(x.to(D), perm.to(D), 4, flip, loss, torch.tensor([0.5], device=D), dlg)
-        assert abs(loss.item() - ref.item()) < 1e-5 and relerr(dlg, xr.grad) < 1e-5
+        dlg = torch.zeros(8, 4, device=D)
+        tg = torch.empty(8, device=D)
+        ops.disc_targets(perm.to(D), 4, flip, tg)
+        assert torch.allclose(tg.cpu(), tgt)
+        xs = torch.zeros(8, 4, device=D); xs[:, 0] = x.to(D)
+        ops.bce_logits(xs, 4, tg, 8, loss, torch.tensor([0.5], device=D), dlg, 4)
+        assert abs(loss.item() - ref.item()) < 1e-5 and relerr(dlg[:, 0], xr.grad) < 1e-5
 
 
 def test_lstm_fwd_bwd_matches_torch_packed():

@@ -137,6 +137,20 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a,
         for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) a[i] += b[i];
 }
 
+// a *= alpha (gradient averaging after the data-parallel all-reduce)
+__global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ a, float alpha, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] *= alpha;
+}
+
+// dst[r, c] += src[r, c] for c < cols with independent row strides (merging gradient pieces of a padded buffer)
+__global__ __launch_bounds__(256) void add_strided_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds, int rows, int cols) {
+    const size_t total = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
+        dst[(size_t)r * ldd + c] += src[(size_t)r * lds + c];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // SpecAugment as the reference implements it (src/utils.py:51-75): per sample, two random TIME spans (widths
 // f ~ U{0..19}, t ~ U{0..99}) are overwritten with that sample's mean over the whole padded [T,M] slab.
@@ -260,6 +274,18 @@ extern "C" int unast_add_inplace(float* a, const float* b, int64_t n, hipStream_
     UNAST_REQUIRE((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "unast_add_inplace: operands must be 16-byte aligned");
     hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_grid((size_t)n / 4 + 1)), dim3(256), 0, stream, a, b, (size_t)n / 4, (size_t)n);
     return unast_check_launch("unast_add_inplace");
+}
+
+extern "C" int unast_scale_inplace(float* a, float alpha, int64_t n, hipStream_t stream) {
+    UNAST_REQUIRE(a && n > 0, "unast_scale_inplace: bad arguments");
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, stream, a, alpha, (size_t)n);
+    return unast_check_launch("unast_scale_inplace");
+}
+
+extern "C" int unast_add_strided(float* dst, int ldd, const float* src, int lds, int rows, int cols, hipStream_t stream) {
+    UNAST_REQUIRE(dst && src && rows > 0 && cols > 0 && ldd >= cols && lds >= cols, "unast_add_strided: bad arguments");
+    hipLaunchKernelGGL(add_strided_kernel, dim3(ew_grid((size_t)rows * cols)), dim3(256), 0, stream, dst, ldd, src, lds, rows, cols);
+    return unast_check_launch("unast_add_strided");
 }
 
 extern "C" int unast_specaugment(const float* mel, const int* lens, float* out, int B, int T, int M, int freq_mask, int time_mask,

@@ -140,20 +140,28 @@ __global__ __launch_bounds__(256) void text_loss_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Discriminator BCE (single block; n = 2B is tiny).  target_i = (perm[i] < B ? 0.9 : 0.1), flipped for the generator.
+// Discriminator targets + BCE (single block; n = 2B is tiny).  target_i = (perm[i] < B ? 1-s : 1-(1-s)), flipped for
+// the generator phase (src/train.py:150-164, 319-320).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void disc_bce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ perm, int n, int B, int flip,
-                                                       float smoothing, const float* __restrict__ gscale, float* __restrict__ loss,
-                                                       float* __restrict__ dlogits) {
+__global__ __launch_bounds__(256) void disc_targets_kernel(const int64_t* __restrict__ perm, int n, int B, int flip, float smoothing, float* __restrict__ out) {
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float y = 1.f - smoothing;
+        if (perm[i] >= B) y = 1.f - y;
+        if (flip) y = 1.f - y;
+        out[i] = y;
+    }
+}
+
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ logits, int ldx, const float* __restrict__ targets, int n,
+                                                         const float* __restrict__ gscale, float* __restrict__ loss, float* __restrict__ dlogits, int ldd) {
     __shared__ float red[4];
     float a = 0.f;
     const float g = gscale ? gscale[0] : 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
-        float y = (perm[i] < B) ? (1.f - smoothing) : 1.f - (1.f - smoothing);
-        if (flip) y = 1.f - y;
-        const float x = logits[i];
+        const float y = targets[i];
+        const float x = logits[(size_t)i * ldx];
         a += (1.f - y) * x + log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f);
-        if (dlogits) dlogits[i] = g * (1.f / (1.f + expf(-x)) - y) / (float)n;
+        if (dlogits) dlogits[(size_t)i * ldd] = g * (1.f / (1.f + expf(-x)) - y) / (float)n;
     }
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
@@ -207,10 +215,16 @@ extern "C" int unast_text_loss_bwd(const float* logits, int ldl, const int64_t* 
     return unast_check_launch("unast_text_loss_bwd");
 }
 
-extern "C" int unast_disc_bce(const float* logits, const int64_t* perm, int n, int B, int flip, float smoothing, const float* gscale,
-                              float* loss, float* dlogits, hipStream_t stream) {
-    UNAST_REQUIRE(logits && perm && n > 0, "unast_disc_bce: bad arguments");
-    UNAST_REQUIRE((dlogits == nullptr) || gscale, "unast_disc_bce: dlogits requires gscale");
-    hipLaunchKernelGGL(disc_bce_kernel, dim3(1), dim3(256), 0, stream, logits, perm, n, B, flip, smoothing, gscale, loss, dlogits);
-    return unast_check_launch("unast_disc_bce");
+extern "C" int unast_disc_targets(const int64_t* perm, int n, int B, int flip, float smoothing, float* out, hipStream_t stream) {
+    UNAST_REQUIRE(perm && out && n > 0, "unast_disc_targets: bad arguments");
+    hipLaunchKernelGGL(disc_targets_kernel, dim3(1), dim3(256), 0, stream, perm, n, B, flip, smoothing, out);
+    return unast_check_launch("unast_disc_targets");
+}
+
+extern "C" int unast_bce_logits(const float* logits, int ldx, const float* targets, int n, const float* gscale, float* loss, float* dlogits,
+                                int ldd, hipStream_t stream) {
+    UNAST_REQUIRE(logits && targets && n > 0 && ldx >= 1, "unast_bce_logits: bad arguments");
+    UNAST_REQUIRE((dlogits == nullptr) || (gscale && ldd >= 1), "unast_bce_logits: dlogits requires gscale and ldd");
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, stream, logits, ldx, targets, n, gscale, loss, dlogits, ldd);
+    return unast_check_launch("unast_bce_logits");
 }

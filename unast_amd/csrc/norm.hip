@@ -173,6 +173,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
 }
 
+// Scalar variant for column counts that are not multiples of 4 (46 phoneme logits, 81 = mel+stop head, 1 = fc2).
+__global__ __launch_bounds__(256) void colsum_scalar_kernel(const float* __restrict__ x, int ldx, int rows, int C, int rows_per_block, float* __restrict__ s1) {
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int r = r0; r < r1; ++r) a += x[(size_t)r * ldx + c];
+        atomicAdd(s1 + c, a);
+    }
+}
+
 // BatchNorm statistics finalize: mean/rstd (biased variance) + running-stat update (momentum, unbiased variance).
 __global__ void bn_finalize_kernel(const double* __restrict__ s1, const double* __restrict__ s2, int C, double n, float eps,
                                    float momentum, float* __restrict__ mean, float* __restrict__ rstd,
@@ -342,7 +352,15 @@ static int colsum_geometry(int rows, int C, int* blocks, int* rpb) {
 extern "C" int unast_colsum_f32(const float* x, int ldx, int rows, int C, float* sum, hipStream_t stream) {
     UNAST_REQUIRE(x && sum, "unast_colsum_f32: null pointer");
     int blocks, rpb;
-    UNAST_REQUIRE(colsum_geometry(rows, C, &blocks, &rpb) == 0 && (ldx & 3) == 0, "unast_colsum_f32: need C%%4==0, C<=1024, ldx%%4==0");
+    UNAST_REQUIRE(rows > 0 && C > 0 && C <= 1024, "unast_colsum_f32: need 0 < C <= 1024");
+    if ((C & 3) != 0 || (ldx & 3) != 0 || (((uintptr_t)x) & 15) != 0) {
+        blocks = grid_for(rows, 64, 1024);
+        rpb = (rows + blocks - 1) / blocks;
+        blocks = (rows + rpb - 1) / rpb;
+        hipLaunchKernelGGL(colsum_scalar_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, rows, C, rpb, sum);
+        return unast_check_launch("unast_colsum_f32");
+    }
+    colsum_geometry(rows, C, &blocks, &rpb);
     hipLaunchKernelGGL((colsum_kernel<float>), dim3(blocks), dim3(256), 0, stream, x, ldx, rows, C, rpb, sum, (float*)nullptr);
     return unast_check_launch("unast_colsum_f32");
 }

@@ -1,0 +1,213 @@
+"""Host-side execution engine: flat parameter/gradient storage, a minimal backward tape, and the bridge that makes
+each public model call one node of torch's autograd graph.
+
+Design (MI355X-first, not a port of the reference's module-by-module autograd):
+  * all parameters of a model live in ONE flat fp32 HBM buffer (and one flat gradient buffer of the same layout), so
+    clip+AdamW is two kernel launches and the data-parallel gradient exchange is a single bucket per phase;
+  * conv weights are stored tap-major [Cout,5,Cin] (the implicit-GEMM K order); the nn.Parameter the user sees is a
+    permuted view with the reference's [Cout,Cin,5] shape, so state_dict round-trips unchanged;
+  * weight-gradient kernels ACCUMULATE into the flat gradient buffer (split-K atomics / +=), the buffer is zeroed
+    once per optimizer phase, and `p.grad` are views into it;
+  * forward code records closures on a Tape; one torch.autograd.Function per public call (`encode`, `decode_sequence`,
+    discriminator forward, each loss) runs the tape in reverse, so `loss.backward()` works as in the reference
+    while every arithmetic kernel is ours.
+"""
+import torch
+
+from . import ops
+
+ALIGN = 64  # floats (256 B) between parameter starts
+
+
+class Var:
+    """An activation and its gradient slot."""
+    __slots__ = ("v", "g")
+
+    def __init__(self, v, g=None):
+        self.v = v
+        self.g = g
+
+
+def acc(var, grad):
+    """Accumulate `grad` into var.g (first writer owns the buffer)."""
+    if grad is None:
+        return
+    if var.g is None:
+        var.g = grad
+    else:
+        ops.add_inplace(var.g, grad)
+
+
+class Tape:
+    def __init__(self):
+        self.fns = []
+
+    def record(self, fn):
+        self.fns.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.fns):
+            fn()
+        self.fns = []
+
+
+class _Segment(torch.autograd.Function):
+    """One public model call = one autograd node; inputs/outputs are torch tensors, the inside is kernels + Tape."""
+
+    @staticmethod
+    def forward(ctx, run, hook, *inputs):
+        tape = Tape()
+        in_vars = [Var(t) if isinstance(t, torch.Tensor) and t.is_floating_point() else t for t in inputs]
+        outs = run(tape, *in_vars)
+        ctx.tape, ctx.in_vars, ctx.out_vars = tape, in_vars, outs
+        res = tuple(o.v for o in outs)
+        return res if len(res) > 1 else res[0]
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        for o, g in zip(ctx.out_vars, gouts):
+            if g is not None and g.dtype != torch.float32:
+                g = g.float()
+            o.g = g
+        ctx.tape.backward()
+        grads = tuple((v.g if isinstance(v, Var) else None) for v in ctx.in_vars)
+        ctx.tape = ctx.in_vars = ctx.out_vars = None
+        return (None, None) + grads
+
+
+def run_segment(run, hook, *inputs):
+    """Executes `run(tape, *vars) -> [Var,...]`.  With grad mode off no tape is kept."""
+    if not torch.is_grad_enabled():
+        in_vars = [Var(t) if isinstance(t, torch.Tensor) and t.is_floating_point() else t for t in inputs]
+        outs = run(None, *in_vars)
+        res = tuple(o.v for o in outs)
+        return res if len(res) > 1 else res[0]
+    return _Segment.apply(run, hook, *inputs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Flat parameter store
+# ---------------------------------------------------------------------------------------------------------------
+def _region_of(name):
+    if name.startswith("discriminator."):
+        return "disc_unused" if ".reduce_c_W." in name else "disc"
+    return "gen"
+
+
+def _layout_order(names):
+    """Physical order: generator params, then discriminator (with the adjacency the kernels rely on), then the
+    never-used reduce_c_W.  Adjacent pairs form single GEMM operands:
+      [linear_project.weight | stop_linear.weight] -> [81,256]; LSTM (fwd | reverse) weights and biases per layer."""
+    gen = [n for n in names if _region_of(n) == "gen"]
+    disc = [n for n in names if _region_of(n) == "disc"]
+    unused = [n for n in names if _region_of(n) == "disc_unused"]
+
+    def move_after(lst, first, second):
+        if first in lst and second in lst:
+            lst.remove(second)
+            lst.insert(lst.index(first) + 1, second)
+    move_after(gen, "speech_m.postnet.linear_project.weight", "speech_m.postnet.stop_linear.weight")
+    move_after(gen, "speech_m.postnet.linear_project.bias", "speech_m.postnet.stop_linear.bias")
+    for n in list(disc):
+        if n.endswith("_reverse"):
+            move_after(disc, n[: -len("_reverse")], n)
+    return gen, disc, unused
+
+
+class FlatStore:
+    """Owns the flat parameter / gradient buffers of one module tree and re-points its nn.Parameters into them."""
+
+    def __init__(self, module, prefix=""):
+        """`prefix` maps a stand-alone sub-model onto canonical names (e.g. "text_m." for a bare TextTransformer)."""
+        named = [(prefix + n, p) for n, p in module.named_parameters()]
+        if not named:
+            raise ValueError("module has no parameters")
+        dev = named[0][1].device
+        if dev.type != "cuda":
+            raise RuntimeError("unast_amd runs on the GPU only: move the model to a CUDA (ROCm) device first; there is no CPU path")
+        self.device = dev
+        self.params = dict(named)
+        gen, disc, unused = _layout_order([n for n, _ in named])
+        self.offsets, self.regions = {}, {}
+        off = 0
+        packed_after = {"speech_m.postnet.linear_project.weight", "speech_m.postnet.linear_project.bias"}
+        for rname, lst in (("gen", gen), ("disc", disc), ("disc_unused", unused)):
+            start = off
+            prev = None
+            for n in lst:
+                tight = prev is not None and (prev in packed_after or (n.endswith("_reverse") and prev == n[: -len("_reverse")]))
+                if not tight:
+                    off = (off + ALIGN - 1) // ALIGN * ALIGN
+                self.offsets[n] = off
+                off += self.params[n].numel()
+                prev = n
+            off = (off + ALIGN - 1) // ALIGN * ALIGN
+            self.regions[rname] = (start, off)
+        self.total = off
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.phys, self.gphys = {}, {}
+        for n, p in self.params.items():
+            o, k = self.offsets[n], p.numel()
+            if n.endswith(".conv.weight"):        # tap-major physical layout [Cout,5,Cin]
+                co, ci, ks = p.shape
+                ph = self.flat[o:o + k].view(co, ks, ci)
+                ph.copy_(p.data.permute(0, 2, 1))
+                p.data = ph.permute(0, 2, 1)
+                self.gphys[n] = self.grad[o:o + k].view(co, ks, ci)
+            else:
+                ph = self.flat[o:o + k].view(p.shape)
+                ph.copy_(p.data)
+                p.data = ph
+                self.gphys[n] = self.grad[o:o + k].view(p.shape)
+            self.phys[n] = ph
+        self.dummy = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)   # forces autograd to call our backward
+        self.touched = set()           # regions that received gradients since the last zero_grad
+        self.grads_exposed = False
+
+    # combined operands ---------------------------------------------------------------------------------------
+    def span(self, first, last, shape, grad=False):
+        """View over consecutive parameters first..last as one tensor of `shape`."""
+        buf = self.grad if grad else self.flat
+        o = self.offsets[first]
+        n = 1
+        for s in shape:
+            n *= s
+        assert o + n <= self.offsets[last] + self.params[last].numel() + 0 and self.offsets[last] + self.params[last].numel() == o + n, \
+            "parameters %s..%s are not contiguous" % (first, last)
+        return buf[o:o + n].view(shape)
+
+    def g(self, name):
+        """Gradient view for `name`, or None when the parameter is frozen (requires_grad=False)."""
+        p = self.params[name]
+        if not p.requires_grad:
+            return None
+        self.touched.add(_region_of(name))
+        return self.gphys[name]
+
+    def gspan(self, first, last, shape):
+        if not self.params[first].requires_grad:
+            return None
+        self.touched.add(_region_of(first))
+        return self.span(first, last, shape, grad=True)
+
+    def expose_grads(self):
+        """Make p.grad views of the flat gradient buffer for every parameter of a touched region (reference
+        semantics: parameters that took no part in the backward keep grad None and are skipped by AdamW)."""
+        for n, p in self.params.items():
+            if _region_of(n) in self.touched and p.requires_grad:
+                gv = self.gphys[n]
+                p.grad = gv.permute(0, 2, 1) if n.endswith(".conv.weight") else gv
+            else:
+                p.grad = None
+
+    def zero_grad(self):
+        for r in self.touched:
+            a, b = self.regions[r]
+            self.grad[a:b].zero_()
+        self.touched = set()
+        for p in self.params.values():
+            p.grad = None
+
+    def active_ranges(self):
+        return [self.regions[r] for r in ("gen", "disc") if r in self.touched]

@@ -1,0 +1,573 @@
+"""Forward + hand-written backward of every block on the UNAST train-step hot path, as sequences of HIP kernel
+launches (unast_amd.ops).  Each function runs the forward immediately and, when a Tape is given, records one closure
+that consumes the gradient of its output Var(s) and produces the gradients of its inputs / parameters.
+
+Reference semantics per block are cited next to each function (file:line in /root/reference).
+Activations are fp32 [B*T, C] row-major (token-major); `lens` are int32 device tensors.
+"""
+import math
+
+import torch
+
+from . import ops
+from .engine import Var, acc
+from .utils import is_deterministic
+
+LN_EPS = 1e-5
+
+
+class Ctx:
+    """Per-call context: parameter store, dropout configuration, RNG stream allocation."""
+
+    def __init__(self, store, training, seed):
+        self.st = store
+        self.P = store.phys
+        self.training = training
+        self.stochastic = training and not is_deterministic()      # dropout / noise sites active
+        self.seed = seed & 0xFFFFFFFF
+        self._stream = 0
+
+    def stream(self):
+        self._stream += 1
+        return self._stream
+
+    def p(self, rate):
+        return float(rate) if self.stochastic else 0.0
+
+
+def _empty(*shape, like=None, device=None):
+    return torch.empty(*shape, dtype=torch.float32, device=(like.device if like is not None else device))
+
+
+def _bias_grad(cx, dy2d, name_or_view):
+    g = cx.st.g(name_or_view) if isinstance(name_or_view, str) else name_or_view
+    if g is not None:
+        ops.colsum(dy2d, g)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Transformer sub-layers (torch.nn.TransformerEncoderLayer / DecoderLayer, post-LN, ReLU; src/module.py:273-274,
+# 286-287; exact math SURVEY.md Appendix A)
+# ---------------------------------------------------------------------------------------------------------------
+def _layernorm(cx, tape, z, pre, x_res_grad_sink):
+    """y = LN(z).  Backward returns (dz, dz_dropped) through `x_res_grad_sink(dz, dzd)`."""
+    rows, C = z.shape
+    y = _empty(rows, C, like=z)
+    mean = _empty(rows, like=z)
+    rstd = _empty(rows, like=z)
+    ops.layernorm_fwd(z, cx.P[pre + "weight"], cx.P[pre + "bias"], y, mean, rstd, LN_EPS)
+    return y, mean, rstd
+
+
+def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, Tk, H, drop):
+    """y = LN(x + dropout(MHA(x, mem or x)))  with attention-probability dropout `drop` as well.
+    x: Var [B*Tq, E]; mem: Var [B*Tk, E] or None for self-attention."""
+    E = x.v.shape[1]
+    Nq, Nk = B * Tq, B * Tk
+    W, bias = cx.P[pre_attn + "in_proj_weight"], cx.P[pre_attn + "in_proj_bias"]
+    Wo, bo = cx.P[pre_attn + "out_proj.weight"], cx.P[pre_attn + "out_proj.bias"]
+    p = cx.p(drop)
+    s_attn, s_out = cx.stream(), cx.stream()
+    if mem is None:
+        qkv = _empty(Nq, 3 * E, like=x.v)
+        ops.linear_fwd(x.v, W, bias, qkv)
+        Q, K, V = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+    else:
+        q = _empty(Nq, E, like=x.v)
+        kv = _empty(Nk, 2 * E, like=x.v)
+        ops.linear_fwd(x.v, W[:E], bias[:E], q)
+        ops.linear_fwd(mem.v, W[E:], bias[E:], kv)
+        Q, K, V = q, kv[:, :E], kv[:, E:]
+    O = _empty(Nq, E, like=x.v)
+    LSE = _empty(B, H, Tq, like=x.v)
+    ops.attn_fwd(Q, K, V, O, LSE, lens_k, B, H, Tq, Tk, causal, drop_p=p, seed=cx.seed, stream_id=s_attn)
+    z = _empty(Nq, E, like=x.v)
+    ops.linear_fwd(O, Wo, bo, z, drop_p=p, seed=cx.seed, stream_id=s_out, R=x.v)          # z = x + drop(O Wo^T + bo)
+    y, mean, rstd = _layernorm(cx, tape, z, pre_norm, None)
+    out = Var(y)
+    if tape is not None:
+        seed = cx.seed
+
+        def bwd():
+            if out.g is None:
+                return
+            st = cx.st
+            dz = _empty(Nq, E, like=z)
+            dzd = _empty(Nq, E, like=z) if p > 0 else None
+            ops.layernorm_bwd(out.g, z, cx.P[pre_norm + "weight"], mean, rstd, dz, dzd, st.g(pre_norm + "weight"), st.g(pre_norm + "bias"),
+                              drop_p=p, seed=seed, stream_id=s_out)
+            da = dzd if p > 0 else dz
+            gWo = st.g(pre_attn + "out_proj.weight")
+            if gWo is not None:
+                ops.linear_wgrad(da, O, gWo)
+                ops.colsum(da, st.g(pre_attn + "out_proj.bias"))
+            dO = _empty(Nq, E, like=z)
+            ops.linear_dgrad(da, Wo, dO)
+            delta = _empty(B, H, Tq, like=z)
+            gW, gb = st.g(pre_attn + "in_proj_weight"), st.g(pre_attn + "in_proj_bias")
+            if mem is None:
+                dqkv = _empty(Nq, 3 * E, like=z)
+                ops.attn_bwd(Q, K, V, O, dO, LSE, delta, dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:], lens_k, B, H, Tq, Tk, causal,
+                             drop_p=p, seed=seed, stream_id=s_attn)
+                if gW is not None:
+                    ops.linear_wgrad(dqkv, x.v, gW)
+                    ops.colsum(dqkv, gb)
+                dx = _empty(Nq, E, like=z)
+                ops.linear_dgrad(dqkv, W, dx, R=dz)
+            else:
+                dq = _empty(Nq, E, like=z)
+                dkv = _empty(Nk, 2 * E, like=z)
+                ops.attn_bwd(Q, K, V, O, dO, LSE, delta, dq, dkv[:, :E], dkv[:, E:], lens_k, B, H, Tq, Tk, causal,
+                             drop_p=p, seed=seed, stream_id=s_attn)
+                if gW is not None:
+                    ops.linear_wgrad(dq, x.v, gW[:E])
+                    ops.linear_wgrad(dkv, mem.v, gW[E:])
+                    ops.colsum(dq, gb[:E])
+                    ops.colsum(dkv, gb[E:])
+                dx = _empty(Nq, E, like=z)
+                ops.linear_dgrad(dq, W[:E], dx, R=dz)
+                dmem = _empty(Nk, E, like=z)
+                ops.linear_dgrad(dkv, W[E:], dmem)
+                acc(mem, dmem)
+            acc(x, dx)
+        tape.record(bwd)
+    return out
+
+
+def ffn_sublayer(cx, tape, x, pre, pre_norm, drop):
+    """y = LN(x + dropout(W2 dropout(relu(W1 x + b1)) + b2))."""
+    N, E = x.v.shape
+    W1, b1, W2, b2 = cx.P[pre + "linear1.weight"], cx.P[pre + "linear1.bias"], cx.P[pre + "linear2.weight"], cx.P[pre + "linear2.bias"]
+    F = W1.shape[0]
+    p = cx.p(drop)
+    s1, s2 = cx.stream(), cx.stream()
+    h = _empty(N, F, like=x.v)
+    ops.linear_fwd(x.v, W1, b1, h, act=1, drop_p=p, seed=cx.seed, stream_id=s1)
+    z = _empty(N, E, like=x.v)
+    ops.linear_fwd(h, W2, b2, z, drop_p=p, seed=cx.seed, stream_id=s2, R=x.v)
+    y, mean, rstd = _layernorm(cx, tape, z, pre_norm, None)
+    out = Var(y)
+    if tape is not None:
+        seed = cx.seed
+
+        def bwd():
+            if out.g is None:
+                return
+            st = cx.st
+            dz = _empty(N, E, like=z)
+            dzd = _empty(N, E, like=z) if p > 0 else None
+            ops.layernorm_bwd(out.g, z, cx.P[pre_norm + "weight"], mean, rstd, dz, dzd, st.g(pre_norm + "weight"), st.g(pre_norm + "bias"),
+                              drop_p=p, seed=seed, stream_id=s2)
+            da = dzd if p > 0 else dz
+            g2 = st.g(pre + "linear2.weight")
+            if g2 is not None:
+                ops.linear_wgrad(da, h, g2)
+                ops.colsum(da, st.g(pre + "linear2.bias"))
+            du = _empty(N, F, like=z)
+            ops.linear_dgrad(da, W2, du, G=h, gate_scale=(1.0 / (1.0 - p) if p > 0 else 1.0))      # relu' and dropout mask from h > 0
+            g1 = st.g(pre + "linear1.weight")
+            if g1 is not None:
+                ops.linear_wgrad(du, x.v, g1)
+                ops.colsum(du, st.g(pre + "linear1.bias"))
+            dx = _empty(N, E, like=z)
+            ops.linear_dgrad(du, W1, dx, R=dz)
+            acc(x, dx)
+        tape.record(bwd)
+    return out
+
+
+def encoder_stack(cx, tape, x, lens, pre, L, B, T, H, drop):
+    """src/module.py:270-280 (TransformerEncoder): all-False attn mask + key padding mask."""
+    for i in range(L):
+        lp = "%s%d." % (pre, i)
+        x = attn_sublayer(cx, tape, x, None, lens, False, lp + "self_attn.", lp + "norm1.", B, T, T, H, drop)
+        x = ffn_sublayer(cx, tape, x, lp, lp + "norm2.", drop)
+    return x
+
+
+def decoder_stack(cx, tape, x, lens_q, mem, lens_k, pre, L, B, Tq, Tk, H, drop):
+    """src/module.py:283-293 (TransformerDecoder): causal + tgt padding self-attention, memory-padding cross-attention."""
+    for i in range(L):
+        lp = "%s%d." % (pre, i)
+        x = attn_sublayer(cx, tape, x, None, lens_q, True, lp + "self_attn.", lp + "norm1.", B, Tq, Tq, H, drop)
+        x = attn_sublayer(cx, tape, x, mem, lens_k, False, lp + "multihead_attn.", lp + "norm2.", B, Tq, Tk, H, drop)
+        x = ffn_sublayer(cx, tape, x, lp, lp + "norm3.", drop)
+    return x
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Positional encoding (src/module.py:249-267; dropout fixed at 0.1)
+# ---------------------------------------------------------------------------------------------------------------
+def posenc(cx, tape, x, pe, T, gate=None):
+    N, Dm = x.v.shape
+    p = cx.p(0.1)
+    s = cx.stream()
+    y = _empty(N, Dm, like=x.v)
+    scale = math.sqrt(Dm)
+    ops.posenc_fwd(x.v, pe, y, T, scale, drop_p=p, seed=cx.seed, stream_id=s)
+    out = Var(y)
+    if tape is not None:
+        seed = cx.seed
+
+        def bwd():
+            if out.g is None:
+                return
+            dx = _empty(N, Dm, like=y)
+            ops.posenc_bwd(out.g, gate, dx, scale, drop_p=p, seed=seed, stream_id=s)
+            acc(x, dx)
+        tape.record(bwd)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Text side
+# ---------------------------------------------------------------------------------------------------------------
+def conv_bn_act(cx, tape, x, B, T, conv_pre, bn_pre, pad_left, act, drop, bn_buffers, residual=None, x_ld_view=None):
+    """dropout(act(BN_train(conv1d_k5(x)))) — one stage of TextPrenet.forward_fcn / SpeechPostnet.forward
+    (src/module.py:162-165, 223-230).  x: Var [B*T, Cin]."""
+    Wp, b = cx.P[conv_pre + "conv.weight"], cx.P[conv_pre + "conv.bias"]
+    Cout, _, Cin = Wp.shape
+    x3 = x.v.view(B, T, -1)[..., :Cin] if x.v.shape[1] != Cin else x.v.view(B, T, Cin)
+    c = _empty(B, T, Cout, like=x.v)
+    ops.conv_fwd(x3, Wp, b, c, pad_left)
+    p = cx.p(drop)
+    s = cx.stream()
+    N = B * T
+    y = _empty(N, Cout, like=x.v)
+    mean, rstd = _empty(Cout, like=x.v), _empty(Cout, like=x.v)
+    ws = torch.empty(2 * Cout, dtype=torch.float64, device=x.v.device)
+    rm, rv = (bn_buffers[bn_pre + "running_mean"], bn_buffers[bn_pre + "running_var"]) if cx.training else (None, None)
+    gamma, beta = cx.P[bn_pre + "weight"], cx.P[bn_pre + "bias"]
+    ops.bn_fwd(c.view(N, Cout), gamma, beta, y, mean, rstd, rm, rv, ws, act, drop_p=p, seed=cx.seed, stream_id=s)
+    if cx.training:
+        bn_buffers[bn_pre + "num_batches_tracked"] += 1
+    out = Var(y)
+    if tape is not None:
+        seed = cx.seed
+
+        def bwd():
+            if out.g is None:
+                return
+            st = cx.st
+            dy = out.g if out.g.is_contiguous() else out.g.contiguous()
+            dc = _empty(N, Cout, like=y)
+            ops.bn_bwd(dy, c.view(N, Cout), mean, rstd, gamma, beta, dc, st.g(bn_pre + "weight"), st.g(bn_pre + "bias"), ws, act,
+                       drop_p=p, seed=seed, stream_id=s)
+            gW = st.g(conv_pre + "conv.weight")
+            dc3 = dc.view(B, T, Cout)
+            if gW is not None:
+                ops.conv_wgrad(dc3, x3, gW, pad_left)
+                ops.colsum(dc, st.g(conv_pre + "conv.bias"))
+            dx = _empty(B, T, Cin, like=y)
+            ops.conv_dgrad(dc3, Wp, dx, pad_left)
+            acc(x, dx.view(N, Cin))
+        tape.record(bwd)
+    return out
+
+
+def text_embed(cx, tape, ids, T, drop, noise, shift_sos):
+    """prenet.emb_dropout(prenet.embed(ids)) [+ noise_fn]  (src/network.py:427-438); shift_sos builds [SOS, ids[:-1]]."""
+    E = cx.P["text_m.prenet.embed.weight"]
+    N = ids.numel()
+    p = cx.p(drop)
+    pn = 0.3 if (noise and cx.stochastic) else 0.0
+    s, sn = cx.stream(), cx.stream()
+    y = _empty(N, E.shape[1], device=E.device)
+    ops.embed_fwd(ids, E, y, T, shift_sos=shift_sos, drop_p=p, seed=cx.seed, stream_id=s, noise_p=pn, noise_stream=sn)
+    out = Var(y)
+    if tape is not None:
+        seed = cx.seed
+
+        def bwd():
+            gE = cx.st.g("text_m.prenet.embed.weight")
+            if out.g is None or gE is None:
+                return
+            ops.embed_bwd(ids, out.g, gE, T, shift_sos=shift_sos, drop_p=p, seed=seed, stream_id=s, noise_p=pn, noise_stream=sn)
+        tape.record(bwd)
+    return out
+
+
+def text_encode(cx, tape, m, ids, lens, noise):
+    """TextTransformer.encode (src/network.py:427-444)."""
+    B, T = ids.shape
+    a = m.args
+    x = text_embed(cx, tape, ids, T, a.t_pre_drop, noise, -1)
+    for i in (1, 2, 3):
+        x = conv_bn_act(cx, tape, x, B, T, "text_m.prenet.conv%d." % i, "text_m.prenet.batch_norm%d." % i, 2, 1, a.t_pre_drop, m.buffers_dict)
+    x = posenc(cx, tape, x, m.pe, T)
+    return encoder_stack(cx, tape, x, lens, "text_m.encoder.transformer_encoder.layers.", a.num_layers, B, T, a.nhead, a.e_drop)
+
+
+def text_decode(cx, tape, m, ids, lens_q, mem, lens_k, Tk):
+    """TextTransformer.decode_sequence (src/network.py:483-493) incl. TextPostnet (src/module.py:233-246).
+    Returns Var logits buffer [B*T, 48] (46 valid columns)."""
+    B, T = ids.shape
+    a = m.args
+    x = text_embed(cx, tape, ids, T, a.t_pre_drop, False, 1)          # SOS_IDX = 1
+    x = posenc(cx, tape, x, m.pe, T)
+    x = decoder_stack(cx, tape, x, lens_q, mem, lens_k, "text_m.decoder.transformer_decoder.layers.", a.num_layers, B, T, Tk, a.nhead, a.d_drop)
+    N, E = x.v.shape
+    p = cx.p(a.t_post_drop)
+    s = cx.stream()
+    if p > 0:
+        xd = _empty(N, E, like=x.v)
+        ops.leaky_dropout(x.v, None, xd, 1.0, drop_p=p, seed=cx.seed, stream_id=s)
+    else:
+        xd = x.v
+    W, b = cx.P["text_m.postnet.fc1.weight"], cx.P["text_m.postnet.fc1.bias"]
+    V = W.shape[0]
+    ldl = (V + 3) // 4 * 4
+    logits = torch.zeros(N, ldl, dtype=torch.float32, device=x.v.device)
+    ops.linear_fwd(xd, W, b, logits[:, :V])
+    out = Var(logits)
+    if tape is not None:
+        seed = cx.seed
+
+        def bwd():
+            if out.g is None:
+                return
+            st = cx.st
+            dl = out.g
+            gW = st.g("text_m.postnet.fc1.weight")
+            if gW is not None:
+                ops.linear_wgrad(dl[:, :V], xd, gW)
+                ops.colsum(dl[:, :V], st.g("text_m.postnet.fc1.bias"))
+            dxd = _empty(N, E, like=xd)
+            ops.linear_dgrad(dl[:, :V], W, dxd)
+            if p > 0:
+                dx = _empty(N, E, like=xd)
+                ops.leaky_dropout(x.v, dxd, dx, 1.0, drop_p=p, seed=seed, stream_id=s)
+            else:
+                dx = dxd
+            acc(x, dx)
+        tape.record(bwd)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Speech side
+# ---------------------------------------------------------------------------------------------------------------
+def speech_prenet(cx, tape, m, mel2d, T):
+    """SpeechPrenet (src/module.py:76-110; ONE dropout) followed by PositionalEncoding."""
+    a = m.args
+    N = mel2d.shape[0]
+    W1, b1 = cx.P["speech_m.prenet.layer.fc1.linear_layer.weight"], cx.P["speech_m.prenet.layer.fc1.linear_layer.bias"]
+    W2, b2 = cx.P["speech_m.prenet.layer.fc2.linear_layer.weight"], cx.P["speech_m.prenet.layer.fc2.linear_layer.bias"]
+    p = cx.p(a.s_pre_drop)
+    s = cx.stream()
+    h1 = _empty(N, W1.shape[0], like=mel2d)
+    ops.linear_fwd(mel2d, W1, b1, h1, act=1, drop_p=p, seed=cx.seed, stream_id=s)
+    h2 = _empty(N, W2.shape[0], like=mel2d)
+    ops.linear_fwd(h1, W2, b2, h2, act=1)
+    h2v = Var(h2)
+    if tape is not None:
+        def bwd():
+            st = cx.st
+            d2 = h2v.g                                  # already gated by relu'(h2) in posenc's backward
+            g2 = st.g("speech_m.prenet.layer.fc2.linear_layer.weight")
+            if d2 is None or g2 is None:
+                return
+            ops.linear_wgrad(d2, h1, g2)
+            ops.colsum(d2, st.g("speech_m.prenet.layer.fc2.linear_layer.bias"))
+            du = _empty(N, W1.shape[0], like=h1)
+            ops.linear_dgrad(d2, W2, du, G=h1, gate_scale=(1.0 / (1.0 - p) if p > 0 else 1.0))
+            ops.linear_wgrad(du, mel2d, st.g("speech_m.prenet.layer.fc1.linear_layer.weight"))
+            ops.colsum(du, st.g("speech_m.prenet.layer.fc1.linear_layer.bias"))
+        tape.record(bwd)                                # recorded before posenc's closure => runs after it
+    y = posenc(cx, tape, h2v, m.pe, T, gate=h2)
+    return y
+
+
+def speech_encode(cx, tape, m, mel, lens, noise):
+    """SpeechTransformer.encode (src/network.py:203-208)."""
+    B, T, M = mel.shape
+    a = m.args
+    mel2d = mel.reshape(B * T, M)
+    if noise and cx.stochastic:
+        noised = _empty(B * T, M, like=mel2d)
+        ops.rowmask(mel2d, noised, 0.3, cx.seed, cx.stream())
+        mel2d = noised
+    x = speech_prenet(cx, tape, m, mel2d, T)
+    return encoder_stack(cx, tape, x, lens, "speech_m.encoder.transformer_encoder.layers.", a.num_layers, B, T, a.nhead, a.e_drop)
+
+
+def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk):
+    """SpeechTransformer.decode_sequence (src/network.py:254-269) + SpeechPostnet (src/module.py:155-171).
+    Returns (head Var [B*T, 84]: cols 0..79 pre-net mel, col 80 stop logit; post Var [B*T, 80])."""
+    B, T, M = mel.shape
+    a = m.args
+    N = B * T
+    tgt = torch.zeros_like(mel)                                    # [zero frame, mel[:-1]]  (device-memory plumbing)
+    tgt[:, 1:] = mel[:, :-1]
+    x = speech_prenet(cx, tape, m, tgt.view(N, M), T)
+    x = decoder_stack(cx, tape, x, lens_q, mem, lens_k, "speech_m.decoder.transformer_decoder.layers.", a.num_layers, B, T, Tk, a.nhead, a.d_drop)
+    E = x.v.shape[1]
+    st = cx.st
+    Wh = st.span("speech_m.postnet.linear_project.weight", "speech_m.postnet.stop_linear.weight", (M + 1, E))
+    bh = st.span("speech_m.postnet.linear_project.bias", "speech_m.postnet.stop_linear.bias", (M + 1,))
+    ldh = (M + 1 + 3) // 4 * 4
+    head = torch.zeros(N, ldh, dtype=torch.float32, device=mel.device)
+    ops.linear_fwd(x.v, Wh, bh, head[:, :M + 1])
+    headv = Var(head)
+    pre = Var(head)                                                 # postnet input = columns [0,M) of head (row stride ldh)
+    postv = Var(None)
+    if tape is not None:
+        def bwd_head():
+            # d(head) = loss part (headv.g) + postnet-input part (pre.g, [N,M]) + residual part of post = pre + postnet(pre)
+            dh = headv.g
+            if dh is None:
+                dh = torch.zeros(N, ldh, dtype=torch.float32, device=mel.device)
+            if pre.g is not None:
+                ops.add_strided(dh, pre.g, M)
+            if postv.g is not None:
+                ops.add_strided(dh, postv.g, M)
+            gW = st.gspan("speech_m.postnet.linear_project.weight", "speech_m.postnet.stop_linear.weight", (M + 1, E))
+            if gW is not None:
+                ops.linear_wgrad(dh[:, :M + 1], x.v, gW)
+                ops.colsum(dh[:, :M + 1], st.gspan("speech_m.postnet.linear_project.bias", "speech_m.postnet.stop_linear.bias", (M + 1,)))
+            dx = _empty(N, E, like=x.v)
+            ops.linear_dgrad(dh[:, :M + 1], Wh, dx)
+            acc(x, dx)
+        tape.record(bwd_head)                                       # runs after every postnet closure
+    y = conv_bn_act(cx, tape, pre, B, T, "speech_m.postnet.conv1.", "speech_m.postnet.pre_batchnorm.", 4, 2, a.s_post_drop, m.buffers_dict)
+    for i in range(3):
+        y = conv_bn_act(cx, tape, y, B, T, "speech_m.postnet.conv_list.%d." % i, "speech_m.postnet.batch_norm_list.%d." % i, 4, 2,
+                        a.s_post_drop, m.buffers_dict)
+    Wp2, b2 = cx.P["speech_m.postnet.conv2.conv.weight"], cx.P["speech_m.postnet.conv2.conv.bias"]
+    post = _empty(B, T, M, like=mel)
+    C = y.v.shape[1]
+    ops.gemm(ops.OP_KC_CONV, ops.OP_KC, y.v, C, Wp2, 5 * C, post, M, N, M, 5 * C, conv=(T, C, 0, 4), bias=b2, R=head, ldr=ldh)   # + residual pre
+    postv.v = post.view(N, M)
+    if tape is not None:
+        def bwd_conv2():
+            if postv.g is None:
+                return
+            dp = postv.g if postv.g.is_contiguous() else postv.g.contiguous()
+            postv.g = dp
+            gW = st.g("speech_m.postnet.conv2.conv.weight")
+            dp3 = dp.view(B, T, M)
+            if gW is not None:
+                ops.conv_wgrad(dp3, y.v.view(B, T, C), gW, 4)
+                ops.colsum(dp, st.g("speech_m.postnet.conv2.conv.bias"))
+            dy = _empty(B, T, C, like=dp)
+            ops.conv_dgrad(dp3, Wp2, dy, 4)
+            acc(y, dy.view(N, C))
+        tape.record(bwd_conv2)                                      # recorded last => runs first
+    return headv, postv
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LSTM discriminator (src/network.py:172-186, src/module.py:297-336)
+# ---------------------------------------------------------------------------------------------------------------
+def lstm_discriminator(cx, tape, m, x, lens, Bd, T, need_input_grad=True):
+    """x: Var [Bd*T, d_in] (zero padded), lens int32 [Bd].  Returns Var logits buffer [Bd, 4] (column 0 valid)."""
+    st = cx.st
+    Hh, L, ndir = m.hidden, m.num_layers, m.num_dir
+    G4 = 4 * Hh
+    dev = x.v.device
+    p_inter = cx.p(m.dropout_p) if L > 1 else 0.0
+    saved = []
+    inp = x
+    hfin = None
+    for l in range(L):
+        names = ["discriminator.rnn.rnn.%s_l%d" % (k, l) for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        last = [n + ("_reverse" if ndir == 2 else "") for n in names]
+        din = inp.v.shape[1]
+        Wih = st.span(names[0], last[0], (ndir * G4, din))
+        Whh = st.span(names[1], last[1], (ndir * G4, Hh))
+        bih = st.span(names[2], last[2], (ndir * G4,))
+        bhh = st.span(names[3], last[3], (ndir * G4,))
+        xproj = _empty(Bd * T, ndir * G4, device=dev)
+        ops.linear_fwd(inp.v, Wih, None, xproj)
+        y = torch.zeros(Bd, T, ndir * Hh, dtype=torch.float32, device=dev)
+        gates = _empty(Bd, T, ndir, G4, device=dev)
+        cs = _empty(Bd, T, ndir, Hh, device=dev)
+        hprev = torch.zeros(Bd, T, ndir, Hh, dtype=torch.float32, device=dev)
+        hfin = _empty(Bd, ndir * Hh, device=dev)
+        ops.lstm_fwd(xproj.view(Bd, T, ndir * G4), Whh, bih, bhh, lens, y, gates, cs, hprev, hfin, ndir, G4 * Hh, G4)
+        yv = Var(y.view(Bd * T, ndir * Hh))
+        rec = dict(l=l, names=names, last=last, Wih=Wih, Whh=Whh, inp=inp, y=yv, gates=gates, cs=cs, hprev=hprev, din=din, drop=None)
+        saved.append(rec)
+        if l + 1 < L:
+            if p_inter > 0:
+                s = cx.stream()
+                yd = _empty(Bd * T, ndir * Hh, device=dev)
+                ops.leaky_dropout(yv.v, None, yd, 1.0, drop_p=p_inter, seed=cx.seed, stream_id=s)
+                rec["drop"] = s
+                inp = Var(yd)
+                rec["next_in"] = inp
+            else:
+                inp = yv
+                rec["next_in"] = inp
+    # head: reduce_h_W on [h_fwd | h_bwd] of the top layer -> LeakyReLU -> Dropout -> fc2
+    p_head = cx.p(m.dropout_p)
+    if ndir == 2:
+        Wr, br = cx.P["discriminator.rnn.reduce_h_W.weight"], cx.P["discriminator.rnn.reduce_h_W.bias"]
+        r = _empty(Bd, Hh, device=dev)
+        ops.linear_fwd(hfin, Wr, br, r)
+    else:
+        r = hfin
+    s_head = cx.stream()
+    a = _empty(Bd, Hh, device=dev)
+    ops.leaky_dropout(r, None, a, m.relu_slope, drop_p=p_head, seed=cx.seed, stream_id=s_head)
+    W2, b2 = cx.P["discriminator.fc2.weight"], cx.P["discriminator.fc2.bias"]
+    logit = torch.zeros(Bd, 4, dtype=torch.float32, device=dev)
+    ops.linear_fwd(a, W2, b2, logit[:, :1])
+    out = Var(logit)
+    if tape is not None:
+        seed = cx.seed
+
+        def bwd():
+            if out.g is None:
+                return
+            dl = out.g                                             # [Bd,4], column 0 valid
+            g2 = st.g("discriminator.fc2.weight")
+            if g2 is not None:
+                ops.linear_wgrad(dl[:, :1], a, g2)
+                ops.colsum(dl[:, :1], st.g("discriminator.fc2.bias"))
+            da = _empty(Bd, Hh, device=dev)
+            ops.linear_dgrad(dl[:, :1], W2, da)
+            dr = _empty(Bd, Hh, device=dev)
+            ops.leaky_dropout(r, da, dr, m.relu_slope, drop_p=p_head, seed=seed, stream_id=s_head)
+            if ndir == 2:
+                gr = st.g("discriminator.rnn.reduce_h_W.weight")
+                if gr is not None:
+                    ops.linear_wgrad(dr, hfin, gr)
+                    ops.colsum(dr, st.g("discriminator.rnn.reduce_h_W.bias"))
+                dhf = _empty(Bd, ndir * Hh, device=dev)
+                ops.linear_dgrad(dr, Wr, dhf)
+            else:
+                dhf = dr
+            dy = None
+            for rec in reversed(saved):
+                dg = torch.zeros(Bd, T, ndir, G4, dtype=torch.float32, device=dev)
+                ops.lstm_bwd(dy, dhf, rec["Whh"], rec["gates"], rec["cs"], lens, dg, ndir, G4 * Hh)
+                dhf = None                                          # only the top layer's final state feeds the head
+                dg2 = dg.view(Bd * T, ndir * G4)
+                names, last = rec["names"], rec["last"]
+                gWih = st.gspan(names[0], last[0], (ndir * G4, rec["din"]))
+                if gWih is not None:
+                    ops.linear_wgrad(dg2, rec["inp"].v, gWih)
+                    gWhh = st.gspan(names[1], last[1], (ndir * G4, Hh))
+                    hp = rec["hprev"].view(Bd * T, ndir * Hh)
+                    for d in range(ndir):
+                        ops.linear_wgrad(dg2[:, d * G4:(d + 1) * G4], hp[:, d * Hh:(d + 1) * Hh], gWhh[d * G4:(d + 1) * G4])
+                    ops.colsum(dg2, st.gspan(names[2], last[2], (ndir * G4,)))
+                    ops.colsum(dg2, st.gspan(names[3], last[3], (ndir * G4,)))
+                need_dx = rec["l"] > 0 or need_input_grad
+                if not need_dx:
+                    break
+                dxin = _empty(Bd * T, rec["din"], device=dev)
+                ops.linear_dgrad(dg2, rec["Wih"], dxin)
+                if rec["l"] > 0:
+                    prev = saved[rec["l"] - 1]
+                    if prev["drop"] is not None:
+                        dyp = _empty(Bd * T, ndir * Hh, device=dev)
+                        ops.leaky_dropout(prev["y"].v, dxin, dyp, 1.0, drop_p=p_inter, seed=seed, stream_id=prev["drop"])
+                        dy = dyp.view(Bd, T, ndir * Hh)
+                    else:
+                        dy = dxin.view(Bd, T, ndir * Hh)
+                else:
+                    acc(x, dxin)
+        tape.record(bwd)
+    return out

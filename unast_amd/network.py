@@ -1,0 +1,419 @@
+"""UNAST task graph, transformer autoencoders and discriminators with the reference's API (src/network.py), executed
+by hand-written HIP kernels.
+
+Public surface kept:
+  UNAST(text_m, speech_m, discriminator=None, teacher=None): text_ae, speech_ae, tts, asr, num_params
+  TextTransformer / SpeechTransformer(args): encode, decode_sequence, forward, preprocess
+  LSTMDiscriminator(d_in, hidden, out=1, bidirectional=False, num_layers=1, dropout=.2, relu=.2).forward(out, out_len)
+  Discriminator(enc_dim, hidden=1024, out_classes=1, dropout=.2, relu=.2).forward(enc_output)
+`state_dict()` keys/shapes equal the reference's (unast_amd.spec).  The `masks` tuple returned by encode() is opaque
+to callers in the reference (only passed back into decode_sequence); here it carries int32 lengths instead of bool
+mask tensors — the kernels test `t < len[b]` themselves (no B x T host loop, cf. src/utils.py:77-83).
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from . import ops
+from .engine import Var, acc, run_segment, FlatStore
+from .module import (SpeechPrenet, SpeechPostnet, TextPrenet, TextPostnet, PositionalEncoding, TransformerEncoder,
+                     TransformerDecoder, RNNEncoder)
+from .spec import state_dict_spec  # noqa: F401  (re-export)
+from .utils import PAD_IDX, SOS_IDX, EOS_IDX, lens_i32, next_seed  # noqa: F401
+
+_HP_KEYS = ("num_mels", "s_pre_hid", "s_pre_drop", "s_post_drop", "t_emb_dim", "t_pre_drop", "t_post_drop", "hidden", "e_in",
+            "e_drop", "d_drop", "num_layers", "nhead", "ffn_dim")
+
+
+def _hp(args):
+    hp = SimpleNamespace(**{k: getattr(args, k) for k in _HP_KEYS if hasattr(args, k)})
+    if hp.hidden != hp.e_in:
+        raise ValueError("hidden must equal e_in (the heads read the decoder output; src/network.py:196 vs src/module.py:152-153)")
+    return hp
+
+
+def _as_padded(t, rows, ld, cols):
+    """Recover (or build) the [rows, ld] padded buffer behind a [..., cols] view; device-memory plumbing only."""
+    if t is None:
+        return None
+    if t.dim() >= 2 and t.stride(-1) == 1 and t.stride(-2) == ld and t.storage_offset() % 4 == 0 and \
+            t.untyped_storage().nbytes() // 4 >= t.storage_offset() + rows * ld:
+        lead = t.shape[:-1].numel()
+        if lead == rows and (t.dim() == 2 or t.stride(0) == t.shape[1] * ld):
+            return t.as_strided((rows, ld), (ld, 1))
+    buf = torch.zeros(rows, ld, dtype=torch.float32, device=t.device)
+    buf[:, :cols].copy_(t.reshape(rows, cols))
+    return buf
+
+
+class _Side(nn.Module):
+    """Shared plumbing of TextTransformer / SpeechTransformer / LSTMDiscriminator: canonical name prefix, parameter
+    store lookup (the enclosing UNAST's store when wrapped), BN buffers by canonical name."""
+    _prefix = ""
+
+    def _root(self):
+        r = self.__dict__.get("_unast_root")
+        return r() if r is not None else None
+
+    def _store(self):
+        root = self._root()
+        if root is not None:
+            return root._store()
+        st = self.__dict__.get("_unast_store")
+        dev = next(self.parameters()).device
+        if st is None or st.device != dev:
+            st = FlatStore(self, prefix=self._prefix)
+            self.__dict__["_unast_store"] = st
+        return st
+
+    @property
+    def buffers_dict(self):
+        d = self.__dict__.get("_bufs")
+        dev = next(self.parameters()).device
+        if d is None or d["__dev"] != dev:
+            d = {self._prefix + n: b for n, b in self.named_buffers()}
+            d["__dev"] = dev
+            self.__dict__["_bufs"] = d
+        return d
+
+    def _ctx(self):
+        return F.Ctx(self._store(), self.training, next_seed())
+
+
+class AutoEncoderNet(_Side):
+    """src/network.py:12-86 (abstract interface)."""
+
+    def preprocess(self, input_, input_lens):
+        raise Exception("Please use a subclass for text or speech")
+
+
+def _out3d(tape, var2d, B, T):
+    """Expose a [B*T, C] Var as a [B, T, C] output Var (a view; its gradient flows back as a view)."""
+    o = Var(var2d.v.view(B, T, var2d.v.shape[1]))
+    if tape is not None:
+        def bwd():
+            if o.g is not None:
+                acc(var2d, (o.g if o.g.is_contiguous() else o.g.contiguous()).view(B * T, -1))
+        tape.record(bwd)
+    return o
+
+
+def _mem_in(tape, mem, B, Tk):
+    """[B,Tk,E] input Var -> [B*Tk,E] Var; its closure (recorded first => runs last) hands the gradient back."""
+    memv = Var(mem.v.contiguous().view(B * Tk, -1))
+    if tape is not None:
+        tape.record(lambda: setattr(mem, "g", None if memv.g is None else memv.g.view(B, Tk, -1)))
+    return memv
+
+
+class TextTransformer(AutoEncoderNet):
+    """src/network.py:417-500."""
+    _prefix = "text_m."
+
+    def __init__(self, args):
+        super().__init__()
+        if args.t_emb_dim != args.e_in:
+            raise ValueError("t_emb_dim must equal e_in (decoder input skips the conv prenet; src/network.py:435-438)")
+        self.prenet = TextPrenet(args.t_emb_dim, args.e_in, p=args.t_pre_drop)
+        self.pos_emb = PositionalEncoding(args.e_in)
+        self.encoder = TransformerEncoder(args.e_in, args.nhead, args.ffn_dim, args.e_drop, args.num_layers)
+        self.decoder = TransformerDecoder(args.e_in, args.nhead, args.ffn_dim, args.d_drop, args.num_layers)
+        self.postnet = TextPostnet(args.hidden, args.t_post_drop)
+        self.args = _hp(args)
+
+    @property
+    def pe(self):
+        return self.pos_emb.pe[0]
+
+    def encode(self, input_, input_lens, noise_in=False):
+        B, T = input_.shape
+        lens = lens_i32(input_lens, input_.device)
+        cx = self._ctx()
+        ids = input_.contiguous()
+
+        def run(tape, dummy):
+            return [_out3d(tape, F.text_encode(cx, tape, self, ids, lens, noise_in), B, T)]
+        enc = run_segment(run, None, cx.st.dummy)
+        return enc, (None, lens)
+
+    def decode_sequence(self, tgt, tgt_lens, enc_outputs, masks, teacher_ratio=1):
+        B, T = tgt.shape
+        Tk = enc_outputs.shape[1]
+        lens_q = lens_i32(tgt_lens, tgt.device)
+        lens_k = masks[1]
+        cx = self._ctx()
+        ids = tgt.contiguous()
+        V = self.postnet.fc1.weight.shape[0]
+
+        def run(tape, dummy, mem):
+            memv = _mem_in(tape, mem, B, Tk)
+            out = F.text_decode(cx, tape, self, ids, lens_q, memv, lens_k, Tk)
+            ldl = out.v.shape[1]
+            o = Var(out.v.view(B, T, ldl)[..., :V])
+            if tape is not None:
+                def bwd():
+                    if o.g is not None:
+                        out.g = _as_padded(o.g, B * T, ldl, V)
+                tape.record(bwd)                                                    # recorded last => runs first
+            return [o]
+        return run_segment(run, None, cx.st.dummy, enc_outputs)
+
+    def postprocess(self, out):
+        raise NotImplementedError("use decode_sequence(); the text post-net is fused into it")
+
+    def forward(self, text, text_len, noise_in=False, teacher_ratio=1, ret_enc_hid=False):
+        enc_outputs, masks = self.encode(text, text_len, noise_in)
+        dec_out = self.decode_sequence(text, text_len, enc_outputs, masks)
+        if ret_enc_hid:
+            return dec_out, enc_outputs
+        return dec_out
+
+    def infer_sequence(self, memory, masks, max_len=300):
+        raise NotImplementedError("autoregressive inference (cross-model step) is a 'next' row: SURVEY.md section 8f-2")
+
+
+class SpeechTransformer(AutoEncoderNet):
+    """src/network.py:188-276."""
+    _prefix = "speech_m."
+
+    def __init__(self, args):
+        super().__init__()
+        self.prenet = SpeechPrenet(args.num_mels, args.s_pre_hid, args.e_in, p=args.s_pre_drop)
+        self.pos_emb = PositionalEncoding(args.e_in)
+        self.encoder = TransformerEncoder(args.e_in, args.nhead, args.ffn_dim, args.e_drop, args.num_layers)
+        self.decoder = TransformerDecoder(args.e_in, args.nhead, args.ffn_dim, args.d_drop, args.num_layers)
+        self.postnet = SpeechPostnet(args.num_mels, args.hidden, p=args.s_post_drop)
+        self.args = _hp(args)
+
+    @property
+    def pe(self):
+        return self.pos_emb.pe[0]
+
+    def encode(self, input_, input_lens, noise_in=False):
+        B, T, M = input_.shape
+        lens = lens_i32(input_lens, input_.device)
+        cx = self._ctx()
+        mel = input_.detach().contiguous()
+
+        def run(tape, dummy):
+            return [_out3d(tape, F.speech_encode(cx, tape, self, mel, lens, noise_in), B, T)]
+        enc = run_segment(run, None, cx.st.dummy)
+        return enc, (None, lens)
+
+    def decode_sequence(self, tgt, tgt_lens, enc_outputs, masks, teacher_ratio=1):
+        B, T, M = tgt.shape
+        Tk = enc_outputs.shape[1]
+        lens_q = lens_i32(tgt_lens, tgt.device)
+        lens_k = masks[1]
+        cx = self._ctx()
+        mel = tgt.detach().contiguous()
+
+        def run(tape, dummy, mem):
+            memv = _mem_in(tape, mem, B, Tk)
+            head, post = F.speech_decode(cx, tape, self, mel, lens_q, memv, lens_k, Tk)
+            ldh = head.v.shape[1]
+            h3 = head.v.view(B, T, ldh)
+            o_pre, o_post, o_stop = Var(h3[..., :M]), Var(post.v.view(B, T, M)), Var(h3[..., M])
+            if tape is not None:
+                def bwd():
+                    if o_post.g is not None:
+                        post.g = (o_post.g if o_post.g.is_contiguous() else o_post.g.contiguous()).view(B * T, M)
+                    gp, gs = o_pre.g, o_stop.g
+                    if gp is None and gs is None:
+                        return
+                    if gp is not None and gs is not None and gp.stride(-1) == 1 and gp.stride(-2) == ldh and \
+                            gs.data_ptr() == gp.data_ptr() + 4 * M and gs.stride(-1) == ldh:
+                        head.g = gp.as_strided((B * T, ldh), (ldh, 1))          # both are views of one d_head buffer
+                    else:
+                        buf = torch.zeros(B * T, ldh, dtype=torch.float32, device=mel.device)
+                        if gp is not None:
+                            buf[:, :M].copy_(gp.reshape(B * T, M))
+                        if gs is not None:
+                            buf[:, M].copy_(gs.reshape(B * T))
+                        head.g = buf
+                tape.record(bwd)                                                    # runs first
+            return [o_pre, o_post, o_stop]
+        pre, post, stop = run_segment(run, None, cx.st.dummy, enc_outputs)
+        return pre, post, stop, tgt_lens
+
+    def postprocess(self, out):
+        raise NotImplementedError("use decode_sequence(); the speech post-net is fused into it")
+
+    def forward(self, mel, mel_len, noise_in=False, teacher_ratio=1, ret_enc_hid=False):
+        enc_outputs, masks = self.encode(mel, mel_len, noise_in)
+        pre_pred, post_pred, stop_pred, stop_lens = self.decode_sequence(mel, mel_len, enc_outputs, masks)
+        if ret_enc_hid:
+            return pre_pred, post_pred, stop_pred, enc_outputs
+        return pre_pred, post_pred, stop_pred
+
+    def infer_sequence(self, memory, masks, max_len=815):
+        raise NotImplementedError("autoregressive inference (cross-model step) is a 'next' row: SURVEY.md section 8f-2")
+
+
+class LSTMDiscriminator(_Side):
+    """src/network.py:172-186."""
+    _prefix = "discriminator."
+
+    def __init__(self, d_in, hidden, out=1, bidirectional=False, num_layers=1, dropout=.2, relu=.2):
+        super().__init__()
+        if hidden != 64 or out != 1:
+            raise NotImplementedError("the persistent LSTM kernel is built for hidden=64, out=1 (disc_hid of every reference config)")
+        self.num_dir = 2 if bidirectional else 1
+        self.num_layers = num_layers
+        self.hidden = hidden
+        self.rnn = RNNEncoder(d_in, hidden, bidirectional=bidirectional, num_layers=num_layers, dropout=dropout)
+        self.fc2 = nn.Linear(hidden, out)
+        self.dropout_p, self.relu_slope = dropout, relu
+
+    def forward(self, out, out_len):
+        Bd, T, Dm = out.shape
+        lens = lens_i32(out_len, out.device)
+        cx = self._ctx()
+        need_dx = out.requires_grad and torch.is_grad_enabled()
+
+        def run(tape, dummy, x):
+            xv = Var(x.v.contiguous().view(Bd * T, Dm))
+            if tape is not None:
+                tape.record(lambda: setattr(x, "g", None if xv.g is None else xv.g.view(Bd, T, Dm)))
+            lg = F.lstm_discriminator(cx, tape, self, xv, lens, Bd, T, need_input_grad=need_dx)
+            o = Var(lg.v[:, 0])
+            if tape is not None:
+                tape.record(lambda: setattr(lg, "g", _as_padded(o.g.unsqueeze(-1), Bd, 4, 1)) if o.g is not None else None)
+            return [o]
+        return run_segment(run, None, cx.st.dummy, out)
+
+
+class Discriminator(_Side):
+    """src/network.py:154-170 (MLP discriminator of Lample et al.; present in the reference but never built by train.py)."""
+    _prefix = "discriminator."
+
+    def __init__(self, enc_dim, hidden=1024, out_classes=1, dropout=.2, relu=.2):
+        super().__init__()
+        self.fc1 = nn.Linear(enc_dim, hidden)
+        self.fc2 = nn.Linear(hidden, hidden)
+        self.fc3 = nn.Linear(hidden, hidden)
+        self.fc4 = nn.Linear(hidden, out_classes)
+        self.dropout_p, self.relu_slope, self.out_classes = dropout, relu, out_classes
+
+    def forward(self, enc_output):
+        shape = enc_output.shape
+        N, Dm = shape[:-1].numel(), shape[-1]
+        cx = self._ctx()
+        st = cx.st
+        oc = self.out_classes
+        ldo = (oc + 3) // 4 * 4
+
+        def run(tape, dummy, x):
+            xv = x.v.contiguous().view(N, Dm)
+            acts, pres = [xv], []
+            p = cx.p(self.dropout_p)
+            streams = []
+            h = xv
+            for i in (1, 2, 3):
+                W, b = cx.P["discriminator.fc%d.weight" % i], cx.P["discriminator.fc%d.bias" % i]
+                u = torch.empty(N, W.shape[0], dtype=torch.float32, device=xv.device)
+                ops.linear_fwd(h, W, b, u)
+                a = torch.empty_like(u)
+                s = cx.stream()
+                ops.leaky_dropout(u, None, a, self.relu_slope, drop_p=p, seed=cx.seed, stream_id=s)
+                pres.append(u); acts.append(a); streams.append(s)
+                h = a
+            W4, b4 = cx.P["discriminator.fc4.weight"], cx.P["discriminator.fc4.bias"]
+            lg = torch.zeros(N, ldo, dtype=torch.float32, device=xv.device)
+            ops.linear_fwd(h, W4, b4, lg[:, :oc])
+            o = Var(lg[:, :oc].view(*shape[:-1], oc).squeeze(-1) if oc == 1 else lg[:, :oc].view(*shape[:-1], oc))
+            if tape is not None:
+                seed = cx.seed
+
+                def bwd():
+                    if o.g is None:
+                        return
+                    d = _as_padded(o.g.reshape(N, oc), N, ldo, oc)
+                    g4 = st.g("discriminator.fc4.weight")
+                    if g4 is not None:
+                        ops.linear_wgrad(d[:, :oc], acts[3], g4)
+                        ops.colsum(d[:, :oc], st.g("discriminator.fc4.bias"))
+                    da = torch.empty_like(acts[3])
+                    ops.linear_dgrad(d[:, :oc], W4, da)
+                    for i in (3, 2, 1):
+                        du = torch.empty_like(da)
+                        ops.leaky_dropout(pres[i - 1], da, du, self.relu_slope, drop_p=p, seed=seed, stream_id=streams[i - 1])
+                        gW = st.g("discriminator.fc%d.weight" % i)
+                        if gW is not None:
+                            ops.linear_wgrad(du, acts[i - 1], gW)
+                            ops.colsum(du, st.g("discriminator.fc%d.bias" % i))
+                        if i == 1 and not x.v.requires_grad:
+                            break
+                        da = torch.empty_like(acts[i - 1])
+                        ops.linear_dgrad(du, cx.P["discriminator.fc%d.weight" % i], da)
+                    else:
+                        x.g = da.view(shape)
+                tape.record(bwd)
+            return [o]
+        return run_segment(run, None, cx.st.dummy, enc_output)
+
+
+class UNAST(_Side):
+    """src/network.py:88-152."""
+
+    def __init__(self, text_m, speech_m, discriminator=None, teacher=None):
+        """NOTE: text_m and speech_m should be same type"""
+        super().__init__()
+        self.text_m = text_m
+        self.speech_m = speech_m
+        self.discriminator = discriminator
+        self.teacher = teacher
+        import weakref
+        for sub in (text_m, speech_m, discriminator):
+            if sub is not None:
+                sub.__dict__["_unast_root"] = weakref.ref(self)
+
+    def _root(self):
+        return None
+
+    def _store(self):
+        st = self.__dict__.get("_unast_store")
+        dev = next(self.parameters()).device
+        if st is None or st.device != dev:
+            st = FlatStore(self, prefix="")
+            self.__dict__["_unast_store"] = st
+        return st
+
+    def text_ae(self, text, text_len, ret_enc_hid=False):
+        return self.text_m.forward(text, text_len, noise_in=True, teacher_ratio=1, ret_enc_hid=ret_enc_hid)
+
+    def speech_ae(self, mel, mel_len, ret_enc_hid=False):
+        return self.speech_m.forward(mel, mel_len, noise_in=True, ret_enc_hid=ret_enc_hid, teacher_ratio=1)
+
+    def tts(self, text, text_len, mel, mel_len, infer=False, ret_enc_hid=False):
+        t_e_o, t_masks = self.text_m.encode(text, text_len)
+        if infer:
+            raise NotImplementedError("tts(infer=True) needs infer_sequence: SURVEY.md section 8f-2")
+        pre_pred, post_pred, stop_pred, stop_lens = self.speech_m.decode_sequence(mel, mel_len, t_e_o, t_masks, teacher_ratio=1)
+        if ret_enc_hid:
+            return pre_pred, post_pred, stop_pred, stop_lens, t_e_o
+        return pre_pred, post_pred, stop_pred, stop_lens
+
+    def asr(self, text, text_len, mel, mel_len, infer=False, ret_enc_hid=False):
+        s_e_o, s_masks = self.speech_m.encode(mel, mel_len)
+        if infer:
+            raise NotImplementedError("asr(infer=True) needs infer_sequence: SURVEY.md section 8f-2")
+        text_pred = self.text_m.decode_sequence(text, text_len, s_e_o, s_masks, teacher_ratio=1)
+        if ret_enc_hid:
+            return text_pred, s_e_o
+        return text_pred
+
+    def cm_text_in(self, text, text_len, ret_enc_hid=False):
+        raise NotImplementedError("cross-model (back-translation) step is a 'next' row: SURVEY.md section 8f-2")
+
+    def cm_speech_in(self, mel, mel_len, ret_enc_hid=False):
+        raise NotImplementedError("cross-model (back-translation) step is a 'next' row: SURVEY.md section 8f-2")
+
+    def num_params(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def expose_grads(self):
+        """Materialise p.grad (views into the flat gradient buffer) for inspection or third-party optimizers."""
+        self._store().expose_grads()

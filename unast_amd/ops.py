@@ -172,6 +172,16 @@ def add_inplace(a, b):
     check(lib().unast_add_inplace(_p(a), _p(b), a.numel(), _stream()), "unast_add_inplace")
 
 
+def scale_inplace(a, alpha):
+    check(lib().unast_scale_inplace(_p(a), float(alpha), a.numel(), _stream()), "unast_scale_inplace")
+
+
+def add_strided(dst2d, src2d, cols):
+    """dst2d[:, :cols] += src2d[:, :cols] (row strides may differ)."""
+    rows = dst2d.shape[0]
+    check(lib().unast_add_strided(_p(dst2d), dst2d.stride(0), _p(src2d), src2d.stride(0), rows, cols, _stream()), "unast_add_strided")
+
+
 def specaugment(mel, lens_i32, out, seed, stream_id, freq_mask=20, time_mask=100):
     B, T, M = mel.shape
     check(lib().unast_specaugment(_p(mel), _p(lens_i32), _p(out), B, T, M, freq_mask, time_mask, seed & 0xFFFFFFFF, stream_id, _stream()),
@@ -214,9 +224,12 @@ def text_loss_bwd(logits2d, gold, V, eos_weight, ws, gscale, dlogits):
                                     _p(dlogits), _stream()), "unast_text_loss_bwd")
 
 
-def disc_bce(logits, perm, B, flip, loss=None, gscale=None, dlogits=None, smoothing=0.1):
-    check(lib().unast_disc_bce(_p(logits), _p(perm), logits.numel(), B, int(flip), smoothing, _p(gscale), _p(loss), _p(dlogits), _stream()),
-          "unast_disc_bce")
+def disc_targets(perm, B, flip, out, smoothing=0.1):
+    check(lib().unast_disc_targets(_p(perm), perm.numel(), B, int(flip), smoothing, _p(out), _stream()), "unast_disc_targets")
+
+
+def bce_logits(logits, ldx, targets, n, loss=None, gscale=None, dlogits=None, ldd=1):
+    check(lib().unast_bce_logits(_p(logits), ldx, _p(targets), n, _p(gscale), _p(loss), _p(dlogits), ldd, _stream()), "unast_bce_logits")
 
 
 # ---- LSTM discriminator ------------------------------------------------------------------------------------

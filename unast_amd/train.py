@@ -1,0 +1,503 @@
+"""The reference's train-step surface (src/train.py) on MI355X.
+
+Same function names, arguments, return values and `losses[...]` keys as the reference:
+  process_batch, masked_mse/text_loss/speech_loss/discriminator_loss/discriminator_target,
+  autoencoder_step, supervised_step, discriminator_step, discriminator_shuffle_batch, discriminator_hidden_to_loss,
+  train_ae_step, train_sp_step, train_discriminator_step, optimizer_step, freeze/unfreeze_model_parameters,
+  get_linear_schedule_with_warmup, get_transformer_paper_schedule, initialize_model, train_step (one outer step of
+  train()'s hot loop, src/train.py:602-655).
+Module globals DEVICE and WRITER are set by the caller, as in the reference (src/train.py:1005-1012).
+
+Differences that are deliberate and MI355X-motivated:
+  * losses are fused HIP kernels (forward scalar + backward dlogits); `.item()` logging reads are deferred: the
+    `losses` dict receives 0-dim device tensors unless `SYNC_LOSSES` is True (the reference syncs 6+ times per sub-step);
+  * `optimizer_step` with the FusedAdamW built by `initialize_model` = global-norm + clip + AdamW in two launches over
+    the flat buffers, preceded by ONE all-reduce of the active gradient range when torch.distributed is initialised;
+  * cm_steps (autoregressive back-translation) is not on this path yet.
+"""
+import math
+import os
+from collections import defaultdict
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .engine import Var, run_segment
+from .network import TextTransformer, SpeechTransformer, UNAST, Discriminator, LSTMDiscriminator, _as_padded
+from .utils import (PAD_IDX, SOS_IDX, EOS_IDX, lens_i32, specaugment, sent_lens_to_mask, get_teacher_ratio, is_deterministic,
+                    set_seed)  # noqa: F401
+
+DEVICE = None
+WRITER = None
+SYNC_LOSSES = False      # True reproduces the reference's per-sub-step `.detach().cpu().item()` host syncs
+
+
+def _dev():
+    return DEVICE if DEVICE is not None else torch.device("cuda")
+
+
+def _log(v):
+    return v.detach().cpu().item() if SYNC_LOSSES else v.detach()
+
+
+def process_batch(batch):
+    """src/train.py:80-94.  gold_stop is kept for API compatibility; the fused speech loss derives it from mel_len."""
+    text, mel, text_len, mel_len = batch
+    dev = _dev()
+    text, mel = text.to(dev, non_blocking=True), mel.to(dev, non_blocking=True)
+    text_len, mel_len = text_len.to(dev, non_blocking=True), mel_len.to(dev, non_blocking=True)
+    gold_mel, gold_char = mel.detach(), text.detach()
+    gold_stop = _GoldStop(mel_len, mel.shape[1])
+    return (text, mel, text_len, mel_len), (gold_char, gold_mel, gold_stop)
+
+
+class _GoldStop:
+    """Lazy stand-in for F.one_hot(mel_len-1, T).float(): the kernels compute `t == len-1` themselves."""
+
+    def __init__(self, mel_len, T):
+        self.mel_len, self.T = mel_len, T
+
+    def to(self, *a, **k):
+        return self
+
+    def dense(self):
+        return torch.nn.functional.one_hot(self.mel_len - 1, self.T).float()
+
+
+#####----- LOSS FUNCTIONS -----#####
+def _scalar_segment(fwd, bwd, *inputs):
+    """loss = fwd() as a 0-dim tensor; backward calls bwd(gscale_device_scalar) -> grads for `inputs`."""
+    dev = inputs[0].device
+    dummy = _dummy(dev)
+
+    def run(tape, dmy, *ins):
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        saved = fwd(loss)
+        o = Var(loss.view(()))
+        if tape is not None:
+            def back():
+                if o.g is None:
+                    return
+                g = o.g.reshape(1).contiguous()
+                grads = bwd(g, saved)
+                for v, gr in zip(ins, grads):
+                    v.g = gr
+            tape.record(back)
+        return [o]
+    return run_segment(run, None, dummy, *inputs)
+
+
+_DUMMIES = {}
+
+
+def _dummy(dev):
+    d = _DUMMIES.get(dev)
+    if d is None:
+        d = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
+        _DUMMIES[dev] = d
+    return d
+
+
+def masked_mse(gold_mel, pred_mel, mel_mask):
+    """src/train.py:100-103 — kept for API completeness (the hot path uses the fused speech_loss)."""
+    raise NotImplementedError("masked_mse is fused into speech_loss (HIP kernel); call speech_loss")
+
+
+def text_loss(gold_char, text_pred, eos_weight=1.0):
+    """src/train.py:105-111.  text_pred is [B, V, T] as in the reference call sites (logits.permute(0, 2, 1))."""
+    B, V, T = text_pred.shape
+    gold = gold_char.to(text_pred.device).contiguous().view(-1)
+    ldl = (V + 3) // 4 * 4
+    lg_btv = text_pred.permute(0, 2, 1)
+
+    def fwd(loss):
+        logits = _as_padded(lg_btv.detach(), B * T, ldl, V)
+        ws = torch.empty(2, dtype=torch.float64, device=loss.device)
+        ops.text_loss_fwd(logits, gold, V, float(eos_weight), ws, loss)
+        return logits, ws
+
+    def bwd(g, saved):
+        logits, ws = saved
+        dl = torch.empty(B * T, ldl, dtype=torch.float32, device=g.device)
+        ops.text_loss_bwd(logits, gold, V, float(eos_weight), ws, g, dl)
+        return (dl.view(B, T, ldl)[..., :V].permute(0, 2, 1),)
+    return _scalar_segment(fwd, bwd, text_pred)
+
+
+def speech_loss(gold_mel, stop_label, pred_mel, post_pred_mel, mel_len, stop_pred, eos_weight=1.0):
+    """src/train.py:113-122.  stop_label is implied by mel_len (one-hot at len-1, src/train.py:88) and not read."""
+    B, T, M = pred_mel.shape
+    ldh = (M + 1 + 3) // 4 * 4
+    gold = gold_mel.to(pred_mel.device).contiguous()
+    lens = lens_i32(mel_len, pred_mel.device)
+    if stop_pred.dim() == 3:
+        stop_pred = stop_pred.squeeze(-1)
+
+    def fwd(loss):
+        pm, sp = pred_mel.detach(), stop_pred.detach()
+        if pm.stride(-1) == 1 and pm.stride(-2) == ldh and sp.data_ptr() == pm.data_ptr() + 4 * M and sp.stride(-1) == ldh \
+                and pm.stride(0) == T * ldh:
+            head = pm.as_strided((B * T, ldh), (ldh, 1))
+        else:
+            head = torch.zeros(B * T, ldh, dtype=torch.float32, device=pm.device)
+            head[:, :M].copy_(pm.reshape(B * T, M))
+            head[:, M].copy_(sp.reshape(B * T))
+        post = post_pred_mel.detach().contiguous()
+        ws = torch.empty(4, dtype=torch.float64, device=loss.device)
+        ops.speech_loss_fwd(gold, head.view(B, T, ldh), post, lens, float(eos_weight), ws, loss)
+        return head, post
+
+    def bwd(g, saved):
+        head, post = saved
+        dh = torch.empty(B, T, ldh, dtype=torch.float32, device=g.device)
+        dp = torch.empty(B, T, M, dtype=torch.float32, device=g.device)
+        ops.speech_loss_bwd(gold, head.view(B, T, ldh), post, lens, float(eos_weight), g, dh, dp)
+        return dh[..., :M], dp, dh[..., M]
+    return _scalar_segment(fwd, bwd, pred_mel, post_pred_mel, stop_pred)
+
+
+def discriminator_loss(output, target):
+    """src/train.py:147-148."""
+    n = output.numel()
+    tgt = target.to(output.device).contiguous()
+    ldx = output.stride(0) if output.dim() == 1 else 1
+
+    def fwd(loss):
+        out = output.detach()
+        ops.bce_logits(out, ldx, tgt, n, loss=loss)
+        return out
+
+    def bwd(g, out):
+        dl = torch.zeros(n, 4, dtype=torch.float32, device=g.device)
+        ops.bce_logits(out, ldx, tgt, n, gscale=g, dlogits=dl, ldd=4)
+        return (dl[:, 0],)
+    return _scalar_segment(fwd, bwd, output)
+
+
+def discriminator_target(batch_size, target_type, smoothing=0.1):
+    """src/train.py:150-164 (host-side constant vector; the hot path builds targets on the device from the permutation)."""
+    target = torch.ones(batch_size).float()
+    target -= smoothing
+    if target_type == 'speech':
+        target = 1 - target
+    return target
+
+
+def check_nan_loss(model, loss, loss_type, *unused):
+    """src/train.py:166-196 without the per-call host sync: non-finite losses are detected where losses are read."""
+    return None
+
+
+#####----- Use these to run a task on a batch ----#####
+def autoencoder_step(model, batch, args, use_dis_loss=False):
+    """src/train.py:199-229."""
+    x, y = batch
+    text, mel, text_len, mel_len = x
+    gold_char, gold_mel, gold_stop = y
+    if use_dis_loss:
+        text_pred, t_hid = model.text_ae(text, text_len, ret_enc_hid=use_dis_loss)
+        text_pred = text_pred.permute(0, 2, 1)
+        pre_pred, post_pred, stop_pred, s_hid = model.speech_ae(mel, mel_len, ret_enc_hid=use_dis_loss)
+        d_batch = discriminator_shuffle_batch(t_hid, text_len, s_hid, mel_len, args.model_type)
+        d_ae_loss, _ = discriminator_hidden_to_loss(model, d_batch, freeze_discriminator=True)
+    else:
+        text_pred = model.text_ae(text, text_len).permute(0, 2, 1)
+        pre_pred, post_pred, stop_pred = model.speech_ae(mel, mel_len)
+    s_ae_loss = speech_loss(gold_mel, gold_stop, pre_pred, post_pred, mel_len, stop_pred, args.s_eos_weight)
+    t_ae_loss = text_loss(gold_char, text_pred, args.t_eos_weight)
+    if use_dis_loss:
+        return t_ae_loss, s_ae_loss, d_ae_loss
+    return t_ae_loss, s_ae_loss
+
+
+def supervised_step(model, batch, args, use_dis_loss=False):
+    """src/train.py:231-259."""
+    x, y = batch
+    text, mel, text_len, mel_len = x
+    gold_char, gold_mel, gold_stop = y
+    mel_aug = mel if is_deterministic() else specaugment(mel, mel_len)
+    if use_dis_loss:
+        pre_pred, post_pred, stop_pred, stop_lens, t_hid = model.tts(text, text_len, mel, mel_len, ret_enc_hid=use_dis_loss)
+        text_pred, s_hid = model.asr(text, text_len, mel_aug, mel_len, ret_enc_hid=use_dis_loss)
+        text_pred = text_pred.permute(0, 2, 1)
+        d_batch = discriminator_shuffle_batch(t_hid, text_len, s_hid, mel_len, args.model_type)
+        d_sp_loss, _ = discriminator_hidden_to_loss(model, d_batch, freeze_discriminator=True)
+    else:
+        pre_pred, post_pred, stop_pred, stop_lens = model.tts(text, text_len, mel, mel_len)
+        text_pred = model.asr(text, text_len, mel_aug, mel_len).permute(0, 2, 1)
+    tts_loss = speech_loss(gold_mel, gold_stop, pre_pred, post_pred, mel_len, stop_pred, args.s_eos_weight)
+    asr_loss = text_loss(gold_char, text_pred, args.t_eos_weight)
+    if use_dis_loss:
+        return asr_loss, tts_loss, d_sp_loss
+    return asr_loss, tts_loss
+
+
+def crossmodel_step(model, batch, args, use_dis_loss=False):
+    raise NotImplementedError("cross-model (back-translation) step: SURVEY.md section 8f-2 ('next' row)")
+
+
+def discriminator_shuffle_batch(t_hid, t_hid_len, s_hid, s_hid_len, model_type, train_discriminator=False):
+    """src/train.py:296-329 for model_type == 'transformer'."""
+    if model_type != 'transformer':
+        raise NotImplementedError("only the transformer family is on the MI355X path")
+    B, Tt, Dm = t_hid.shape
+    Ts = s_hid.shape[1]
+    Tmax = max(Tt, Ts)
+    dev = t_hid.device
+    perm = torch.arange(2 * B, device=dev) if is_deterministic() else torch.randperm(2 * B, device=dev)
+    tl, sl = lens_i32(t_hid_len, dev), lens_i32(s_hid_len, dev)
+    d_len = torch.empty(2 * B, dtype=torch.int32, device=dev)
+    d_target = torch.empty(2 * B, dtype=torch.float32, device=dev)
+    ops.disc_targets(perm, B, not train_discriminator, d_target)
+
+    def run(tape, dummy, th, sh):
+        thc, shc = th.v.contiguous(), sh.v.contiguous()
+        out = torch.empty(2 * B, Tmax, Dm, dtype=torch.float32, device=dev)
+        ops.disc_gather(thc, shc, tl, sl, perm, out, d_len)
+        o = Var(out)
+        if tape is not None:
+            def bwd():
+                if o.g is None:
+                    return
+                g = o.g if o.g.is_contiguous() else o.g.contiguous()
+                dth = torch.empty(B, Tt, Dm, dtype=torch.float32, device=dev)
+                dsh = torch.empty(B, Ts, Dm, dtype=torch.float32, device=dev)
+                ops.disc_scatter(g, perm, dth, dsh)
+                th.g, sh.g = dth, dsh
+            tape.record(bwd)
+        return [o]
+    if t_hid.requires_grad or s_hid.requires_grad:
+        d_hid = run_segment(run, None, _dummy(dev), t_hid, s_hid)
+    else:
+        with torch.no_grad():
+            d_hid = run_segment(run, None, _dummy(dev), t_hid, s_hid)
+    return (d_hid, d_len, d_target)
+
+
+def discriminator_hidden_to_loss(model, d_batch, freeze_discriminator=False):
+    """src/train.py:331-335."""
+    d_hid, d_len, d_target = d_batch
+    d_out = model.discriminator(d_hid, d_len)
+    d_loss = discriminator_loss(d_out, d_target)
+    return d_loss, (d_out, d_target)
+
+
+def discriminator_step(model, batch, args):
+    """src/train.py:337-354."""
+    x, _ = batch
+    text, mel, text_len, mel_len = x
+    with torch.no_grad():
+        t_enc_out, _ = model.text_m.encode(text, text_len)
+        s_enc_out, _ = model.speech_m.encode(mel, mel_len)
+    d_batch = discriminator_shuffle_batch(t_enc_out, text_len, s_enc_out, mel_len, args.model_type, train_discriminator=True)
+    d_loss, d_output = discriminator_hidden_to_loss(model, d_batch)
+    return d_loss, d_output
+
+
+#####---- Use these to train on a task -----#####
+def optimizer_step(model, optimizer, args):
+    """src/train.py:358-363: clip_grad_norm_ -> optimizer.step() -> zero_grad(set_to_none=True)."""
+    if isinstance(optimizer, FusedAdamW):
+        optimizer.step(max_norm=float(args.grad_clip))
+        optimizer.zero_grad(set_to_none=True)
+        return
+    model.expose_grads()
+    if args.grad_clip > 0.0:
+        nn.utils.clip_grad_norm_(model.parameters(), args.grad_clip)
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    model._store().zero_grad()
+
+
+def train_sp_step(losses, model, batch, step, accum_steps, args):
+    """src/train.py:365-390."""
+    batch = process_batch(batch)
+    if args.use_discriminator:
+        asr_loss, tts_loss, d_sp_loss = supervised_step(model, batch, args, args.use_discriminator)
+        loss = tts_loss + asr_loss + d_sp_loss
+    else:
+        asr_loss, tts_loss = supervised_step(model, batch, args)
+        loss = tts_loss + asr_loss
+    loss = loss / accum_steps
+    loss.backward()
+    losses['asr_'].append(_log(asr_loss))
+    losses['tts_'].append(_log(tts_loss))
+    if args.use_discriminator:
+        losses['sp_d'].append(_log(d_sp_loss))
+    return loss
+
+
+def train_ae_step(losses, model, batch, step, accum_steps, args):
+    """src/train.py:392-416."""
+    batch = process_batch(batch)
+    if args.use_discriminator:
+        t_ae_loss, s_ae_loss, d_ae_loss = autoencoder_step(model, batch, args, args.use_discriminator)
+        loss = t_ae_loss + s_ae_loss + d_ae_loss
+    else:
+        t_ae_loss, s_ae_loss = autoencoder_step(model, batch, args)
+        loss = t_ae_loss + s_ae_loss
+    loss = loss / accum_steps
+    loss.backward()
+    losses['t_ae'].append(_log(t_ae_loss))
+    losses['s_ae'].append(_log(s_ae_loss))
+    if args.use_discriminator:
+        losses['d_ae'].append(_log(d_ae_loss))
+    return loss
+
+
+def train_cm_step(losses, model, batch, step, accum_steps, args):
+    raise NotImplementedError("cross-model (back-translation) step: SURVEY.md section 8f-2 ('next' row)")
+
+
+def train_discriminator_step(losses, model, batch, step, accum_steps, args, log_out_to_tb=False):
+    """src/train.py:446-463."""
+    batch = process_batch(batch)
+    d_loss, d_output = discriminator_step(model, batch, args)
+    loss = d_loss / accum_steps
+    loss.backward()
+    losses['d'].append(_log(d_loss))
+    return loss
+
+
+def freeze_model_parameters(model):
+    """src/train.py:465-467."""
+    for param in model.parameters():
+        param.requires_grad = False
+
+
+def unfreeze_model_parameters(model):
+    """src/train.py:469-471."""
+    for param in model.parameters():
+        param.requires_grad = True
+
+
+def train_step(losses, model, optimizer, scheduler, batches, step, args):
+    """One iteration of the hot loop of train() (src/train.py:602-655) with cm_steps = 0.
+    `batches` = dict(unsup=[...ae_steps batches], sup=[...sp_steps], disc=[...d_steps])."""
+    model.train()
+    if args.use_discriminator:
+        freeze_model_parameters(model.discriminator)
+    accum_steps = args.ae_steps + getattr(args, "cm_steps", 0) + args.sp_steps
+    if getattr(args, "cm_steps", 0):
+        raise NotImplementedError("cm_steps > 0: SURVEY.md section 8f-2")
+    for si in range(args.ae_steps):
+        train_ae_step(losses, model, batches["unsup"][si], step, accum_steps, args)
+    for si in range(args.sp_steps):
+        train_sp_step(losses, model, batches["sup"][si], step, accum_steps, args)
+    optimizer_step(model, optimizer, args)
+    if args.use_discriminator:
+        unfreeze_model_parameters(model.discriminator)
+        for si in range(args.d_steps):
+            train_discriminator_step(losses, model, batches["disc"][si], step, args.d_steps, args)
+        optimizer_step(model, optimizer, args)
+    if scheduler is not None:
+        scheduler.step()
+
+
+#####----- Model, optimizer, scheduler initializations -----#####
+def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, last_epoch=-1):
+    """src/train.py:859-884."""
+    def lr_lambda(current_step: int):
+        if current_step < num_warmup_steps:
+            return float(current_step) / float(max(1, num_warmup_steps))
+        return max(0.0, float(num_training_steps - current_step) / float(max(1, num_training_steps - num_warmup_steps)))
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda, last_epoch)
+
+
+def get_transformer_paper_schedule(optimizer, num_warmup_steps, last_epoch=-1):
+    """src/train.py:886-907 (note: lr = 0 at step 0)."""
+    def lr_lambda(current_step: int):
+        if current_step < num_warmup_steps:
+            return float(current_step) / max(1.0, float(num_warmup_steps) ** 1.5)
+        return 1.0 / max(1.0, float(current_step) ** 0.5)
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda, last_epoch)
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.Adam(W) semantics (src/train.py:929-932) over the model's flat buffers: one sum-of-squares launch per
+    active range + one clip+AdamW launch per range.  Ranges without gradients in this phase (frozen discriminator in the
+    generator phase, generator under no_grad in the D phase, never-used reduce_c_W) are skipped entirely — the
+    `grad is None => skip` behaviour the reference relies on.  Works with torch LR schedulers (param_groups[0]['lr'])."""
+
+    def __init__(self, model, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, decoupled=True):
+        self.model = model
+        super().__init__(list(model.parameters()), dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps))
+        self.decoupled = decoupled
+        self._m = self._v = None
+        self._steps = defaultdict(int)
+        self._ss = None
+        self.last_grad_norm_sq = None
+
+    def _buffers(self, st):
+        if self._m is None or self._m.device != st.flat.device or self._m.numel() != st.total:
+            self._m = torch.zeros_like(st.flat)
+            self._v = torch.zeros_like(st.flat)
+            self._ss = torch.zeros(1, dtype=torch.float64, device=st.flat.device)
+
+    @torch.no_grad()
+    def step(self, max_norm=0.0, closure=None):
+        st = self.model._store()
+        self._buffers(st)
+        ranges = st.active_ranges()
+        if not ranges:
+            return
+        allreduce_grads(st, ranges)
+        g = self.param_groups[0]
+        self._ss.zero_()
+        for a, b in ranges:
+            ops.sumsq(st.grad[a:b], self._ss)
+        self.last_grad_norm_sq = self._ss
+        if not self.decoupled:
+            raise NotImplementedError("optim_type 'adam' (L2-coupled decay) is not built; every reference transformer config uses adamw")
+        for a, b in ranges:
+            self._steps[(a, b)] += 1
+            ops.adamw(st.flat[a:b], st.grad[a:b], self._m[a:b], self._v[a:b], self._ss, float(max_norm), float(g["lr"]),
+                      g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps[(a, b)])
+
+    def zero_grad(self, set_to_none=True):
+        self.model._store().zero_grad()
+
+    def grad_norm(self):
+        """Pre-clip global gradient norm of the last step (one host read; for logging/tests)."""
+        return math.sqrt(float(self.last_grad_norm_sq.item()))
+
+
+def allreduce_grads(st, ranges):
+    """Data-parallel gradient exchange (new vs. the single-device reference): ONE RCCL all-reduce
+    per active contiguous gradient range, averaged over ranks; no-op when torch.distributed is not initialised."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    ws = dist.get_world_size()
+    for a, b in ranges:
+        buf = st.grad[a:b]
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        ops.scale_inplace(buf, 1.0 / ws)
+
+
+def initialize_model(args):
+    """src/train.py:910-959 for model_type == 'transformer'."""
+    if args.model_type != 'transformer':
+        raise NotImplementedError("only model_type='transformer' is on the MI355X path (SURVEY.md section 2, row 11)")
+    text_m, speech_m, discriminator, teacher = TextTransformer(args), SpeechTransformer(args), None, get_teacher_ratio(args)
+    if args.use_discriminator:
+        discriminator = LSTMDiscriminator(args.hidden, args.disc_hid, bidirectional=args.disc_bidirectional, num_layers=args.disc_num_layers)
+    model = UNAST(text_m, speech_m, discriminator, teacher).to(_dev())
+    if args.optim_type not in ('adam', 'adamw'):
+        raise ValueError("optim_type must be adam or adamw")
+    optimizer = FusedAdamW(model, lr=args.lr, weight_decay=args.weight_decay, decoupled=(args.optim_type == 'adamw'))
+    s_epoch, best = 0, 300
+    if getattr(args, "load_path", None) is not None and os.path.isfile(args.load_path):
+        from .checkpoint import load_ckp
+        s_epoch, best, model, optimizer = load_ckp(args.load_path, model, optimizer)
+    scheduler = None
+    if args.sched_type == 'multistep':
+        milestones = [i * args.epoch_steps for i in args.lr_milestones]
+        scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma=args.lr_gamma, last_epoch=s_epoch * args.epoch_steps - 1)
+    elif args.sched_type == 'linear':
+        scheduler = get_linear_schedule_with_warmup(optimizer, args.warmup_steps, args.epochs * args.epoch_steps, s_epoch * args.epoch_steps - 1)
+    elif args.sched_type == 'transformer':
+        scheduler = get_transformer_paper_schedule(optimizer, args.warmup_steps, s_epoch * args.epoch_steps - 1)
+    model.teacher.iter = s_epoch
+    return s_epoch, best, model, optimizer, scheduler
