@@ -53,7 +53,7 @@ static inline uint32_t drop_threshold(float p) {
 // ---------------------------------------------------------------------------------------------
 // fp32 -> bf16 operand preparation for MFMA.
 //   NSPLIT==1: one bf16 (round to nearest even).
-//   NSPLIT==3: x = hi + lo with hi = truncated top 16 bits (exact), lo = RNE(x - hi); the product
+//   NSPLIT==3: x = hi + lo with hi = RNE_bf16(x), lo = RNE_bf16(x - hi); the product
 //              a*b is then formed as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (fp32 accumulate), which
 //              keeps ~16 mantissa bits per operand.
 // ---------------------------------------------------------------------------------------------
@@ -67,17 +67,15 @@ __device__ __forceinline__ uint32_t pack_bf16_trunc(float a, float b) {
 }
 template <int NSPLIT>
 __device__ __forceinline__ void split4(const float4& v, u32x2& hi, u32x2& lo) {
+    hi[0] = pack_bf16_rne(v.x, v.y);
+    hi[1] = pack_bf16_rne(v.z, v.w);
     if (NSPLIT == 1) {
-        hi[0] = pack_bf16_rne(v.x, v.y);
-        hi[1] = pack_bf16_rne(v.z, v.w);
         lo[0] = 0; lo[1] = 0;
-    } else {
-        hi[0] = pack_bf16_trunc(v.x, v.y);
-        hi[1] = pack_bf16_trunc(v.z, v.w);
-        float rx = v.x - __uint_as_float(__float_as_uint(v.x) & 0xFFFF0000u);
-        float ry = v.y - __uint_as_float(__float_as_uint(v.y) & 0xFFFF0000u);
-        float rz = v.z - __uint_as_float(__float_as_uint(v.z) & 0xFFFF0000u);
-        float rw = v.w - __uint_as_float(__float_as_uint(v.w) & 0xFFFF0000u);
+    } else {        // residuals against the ROUNDED hi parts (zero-mean error; exact in fp32), rounded to bf16 in turn
+        const float rx = v.x - __uint_as_float(hi[0] << 16);
+        const float ry = v.y - __uint_as_float(hi[0] & 0xFFFF0000u);
+        const float rz = v.z - __uint_as_float(hi[1] << 16);
+        const float rw = v.w - __uint_as_float(hi[1] & 0xFFFF0000u);
         lo[0] = pack_bf16_rne(rx, ry);
         lo[1] = pack_bf16_rne(rz, rw);
     }
