@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Benchmark of the UNAST adversarial train step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 is launched by the driver as torch.distributed.run (one rank per GPU, RCCL); per-GPU batch is fixed (weak scaling).
+
+One "step" = one iteration of the reference's hot loop with ae_steps = sp_steps = d_steps = 1, cm_steps = 0
+(src/train.py:602-655): freeze(D) -> AE fwd+bwd (+adversarial term) -> SP fwd+bwd (+adversarial term) -> clip+AdamW ->
+unfreeze(D) -> D step fwd+bwd -> clip+AdamW -> scheduler.step(); training mode with every dropout/noise/SpecAugment site
+active; synthetic LJSpeech-shaped full-length batch (B=32, T_text=180, T_mel=800, 80 mels), random-init weights of the
+transformer_d_trans architecture (L=4, d=256, 4 heads, FFN 1024, 2-layer bi-LSTM discriminator).
+value = B * T_mel * n_gpus / step-time  [mel-frames/s].
+
+Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline` (dominant kernel, HIP events recorded
+inside the timed region on the launch stream) and `cpu_baseline` (the pinned oracle timed on the host cores on a bounded
+sample of the same workload; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import defaultdict
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# dense bf16 MFMA peak and HBM peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
+PEAK_MFMA_BF16_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (B, Tt, Tm, L, use_discriminator)
+    "c3": (32, 180, 800, 4, True),      # BASELINE.json configs[2]: the configuration the metric is quoted on
+    "c2": (8, 128, 512, 3, False),      # configs[1]: generator-only
+    "c5": (32, 300, 2000, 4, True),     # configs[4]: long-form
+    "tiny": (2, 24, 64, 2, True),
+}
+
+
+class OpTimer:
+    """Wraps selected unast_amd.ops entry points with HIP event pairs on the launch stream (torch's current stream is the
+    stream every kernel of this package is launched on)."""
+
+    def __init__(self, ops_mod, names):
+        self.ops, self.names = ops_mod, names
+        self.orig, self.events, self.meta = {}, defaultdict(list), {}
+
+    def __enter__(self):
+        for n in self.names:
+            f = getattr(self.ops, n)
+            self.orig[n] = f
+
+            def wrapped(*a, __f=f, __n=n, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = __f(*a, **k)
+                e1.record()
+                self.events[__n].append((e0, e1, self._key(__n, a, k)))
+                return r
+            setattr(self.ops, n, wrapped)
+        return self
+
+    def _key(self, n, a, k):
+        if n == "gemm":
+            # (a_mode, b_mode, M, N, K)
+            return (a[0], a[1], a[8], a[9], a[10])
+        if n in ("attn_fwd", "attn_bwd"):
+            idx = 6 if n == "attn_fwd" else 11
+            return tuple(int(x) for x in a[idx:idx + 5])          # B, H, Tq, Tk, causal
+        return ()
+
+    def __exit__(self, *exc):
+        for n, f in self.orig.items():
+            setattr(self.ops, n, f)
+
+    def summary(self):
+        """{op: {key: (calls, total_ms)}} after a device synchronize."""
+        out = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+        for n, evs in self.events.items():
+            for e0, e1, key in evs:
+                rec = out[n][key]
+                rec[0] += 1
+                rec[1] += e0.elapsed_time(e1)
+        return out
+
+
+def gemm_flops(key):
+    _, _, M, N, K = key
+    return 2.0 * M * N * K
+
+
+def attn_flops(name, key):
+    B, H, Tq, Tk, causal = key
+    pairs = Tq * (Tq + 1) / 2 if causal else Tq * Tk
+    per = 4.0 * B * H * pairs * 64               # QK^T + PV
+    return per if name == "attn_fwd" else per * 2.5      # backward: 5 products (S, dP, dV, dK, dQ)
+
+
+def make_batch(B, Tt, Tm, seed):
+    from unast_amd.portable import synth_batch
+    return tuple(torch.from_numpy(x) for x in synth_batch(B, Tt, Tm, seed=seed, ragged=False))
+
+
+def cpu_baseline(Tt, Tm, L, use_disc, budget_s):
+    """Oracle (CPU restatement, pinned against the reference's golden vectors) timed on the host cores."""
+    from oracle import unast_ref as R
+    from unast_amd.portable import portable_tensor
+    from unast_amd.spec import state_dict_spec
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bs = 1
+    sd = {k: torch.from_numpy(portable_tensor(k, shp, 1234)) for k, shp in state_dict_spec(L, use_discriminator=use_disc).items()}
+    m = R.Model(sd, L)
+    opt = R.AdamW(m.P, lr=1e-3, weight_decay=1e-6)
+    batch = make_batch(Bs, Tt, Tm, 0)
+    t0 = time.time()
+    R.full_step(m, opt, batch, use_discriminator=use_disc)
+    dt = time.time() - t0
+    return {"value": Bs * Tm / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": "1 full gen+disc step of the same workload at B=%d (T_text=%d, T_mel=%d, L=%d), fp32 torch-CPU oracle, %.1f s" % (Bs, Tt, Tm, L, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default=os.environ.get("UNAST_PREC", "bf16x3"), choices=["bf16x3", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-ops", action="store_true", help="time every op family (adds event overhead; not for the headline number)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from unast_amd import config, ops, train, utils
+    from unast_amd.configs import make_args
+    config.set_precision(a.precision)
+    B, Tt, Tm, L, use_disc = WORKLOADS[a.workload]
+    args = make_args(num_layers=L, ae_steps=1, sp_steps=1, d_steps=1, cm_steps=0, use_discriminator=use_disc)
+    train.DEVICE = dev
+    utils.set_seed(1234)                      # identical random-init weights on every rank
+    utils.set_deterministic(False)
+    _, _, model, opt, sched = train.initialize_model(args)
+    utils.set_seed(1234 + rank)               # per-rank dropout / noise / permutation streams
+    batch = make_batch(B, Tt, Tm, seed=rank)
+    batch = tuple(t.to(dev) for t in batch)   # inputs resident in HBM before the timed region
+    batches = dict(unsup=[batch], sup=[batch], disc=[batch])
+    losses = defaultdict(list)
+
+    def one_step(i):
+        train.train_step(losses, model, opt, sched, batches, i, args)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(a.warmup):
+        one_step(i)
+    timed = ["gemm", "attn_fwd", "attn_bwd"]
+    if a.profile_ops:
+        timed += ["layernorm_fwd", "layernorm_bwd", "colsum", "bn_fwd", "bn_bwd", "embed_fwd", "embed_bwd", "posenc_fwd", "posenc_bwd", "rowmask",
+                  "add_inplace", "add_strided", "specaugment", "disc_gather", "disc_scatter", "speech_loss_fwd", "speech_loss_bwd", "text_loss_fwd",
+                  "text_loss_bwd", "bce_logits", "disc_targets", "lstm_fwd", "lstm_bwd", "leaky_dropout", "sumsq", "adamw", "scale_inplace"]
+    sync()
+    with OpTimer(ops, timed) as ot:
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            one_step(a.warmup + i)
+        sync()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / a.steps * 1e3
+    frames = B * Tm * world
+    value = frames / (dt / a.steps)
+
+    last = {k: float(v[-1]) for k, v in losses.items()}
+    finite = all(v == v and abs(v) < 1e30 for v in last.values())
+    if rank != 0:
+        return
+    summ = ot.summary()
+    # ---- dominant kernel family + roofline ------------------------------------------------------------------
+    fam = {}
+    for n in ("gemm", "attn_fwd", "attn_bwd"):
+        calls = sum(v[0] for v in summ[n].values())
+        tot = sum(v[1] for v in summ[n].values())
+        fl = sum((gemm_flops(k) if n == "gemm" else attn_flops(n, k)) * v[0] for k, v in summ[n].items())
+        fam[n] = dict(calls=calls, ms=tot, flops=fl)
+    dom = max(fam, key=lambda n: fam[n]["ms"])
+    d = fam[dom]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    kernel_name = {"gemm": "gemm_kernel<*,*,%d> (all linear/conv contractions)" % config.NSPLIT,
+                   "attn_fwd": "attn_q_kernel<%d,0>" % config.NSPLIT, "attn_bwd": "attn_q_kernel<%d,1> + attn_dkv_kernel<%d>" % (config.NSPLIT, config.NSPLIT)}[dom]
+    roofline = {"kernel": kernel_name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
+                "launches_per_step": d["calls"] / a.steps, "avg_launch_us": round(d["ms"] * 1e3 / max(d["calls"], 1), 2),
+                "mfma_issue_frac": round(ach * config.NSPLIT / PEAK_MFMA_BF16_TFLOPS, 4),
+                "note": "achieved = algorithmic FLOPs (2MNK per contraction; 4*B*H*Tq*Tk*64 per attention forward, x2.5 backward) / HIP-event time of "
+                        "these launches inside the timed region; each algorithmic product costs %d bf16 MFMAs in %s mode (mfma_issue_frac counts them)" % (config.NSPLIT, a.precision),
+                "families_ms_per_step": {n: round(fam[n]["ms"] / a.steps, 3) for n in fam}}
+    out = {"metric": "mel-frames/sec/node (train step, gen+disc) at B=32,T_mel=800; 1/2/4/8-GPU scaling",
+           "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16x3" if config.NSPLIT == 3 else "bf16", "data": "synthetic",
+           "config": {"workload": "%s: full adversarial gen+disc train step (AE+SP+clip/AdamW, D step+clip/AdamW), per-GPU B=%d, T_text=%d, T_mel=%d, "
+                                  "num_layers=%d, d=256, 4 heads, FFN 1024, 2x bi-LSTM(64) discriminator, dropout/noise/SpecAugment active" % (a.workload, B, Tt, Tm, L),
+                      "global_batch": B * world, "parallelism": "dp%d" % world,
+                      "precision": "split-bf16 (hi/lo) MFMA operands, fp32 accumulate and fp32 activations" if config.NSPLIT == 3 else "bf16 MFMA operands, fp32 accumulate"},
+           "losses_finite": finite, "last_losses": {k: round(v, 5) for k, v in last.items()},
+           "roofline": roofline}
+    if world == 1 and not a.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(Tt, Tm, L, use_disc, 30.0)
+        except Exception as e:  # the checker must never take the bench down
+            out["cpu_baseline"] = {"error": repr(e)}
+    if a.profile_ops:
+        prof = {n: round(sum(v[1] for v in summ[n].values()) / a.steps, 3) for n in summ}
+        sys.stderr.write("per-op ms/step: " + json.dumps(dict(sorted(prof.items(), key=lambda kv: -kv[1]))) + "\n")
+        for n in ("gemm", "attn_fwd", "attn_bwd"):
+            rows = sorted(summ[n].items(), key=lambda kv: -kv[1][1])[:12]
+            for k, v in rows:
+                fl = (gemm_flops(k) if n == "gemm" else attn_flops(n, k))
+                sys.stderr.write("  %-9s %-28s calls/step %5.1f  avg %8.1f us  %7.1f TF/s\n" % (n, k, v[0] / a.steps, v[1] * 1e3 / v[0], fl * v[0] / (v[1] * 1e-3) / 1e12))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

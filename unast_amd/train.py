@@ -463,17 +463,23 @@ class FusedAdamW(torch.optim.Optimizer):
         return math.sqrt(float(self.last_grad_norm_sq.item()))
 
 
-def allreduce_grads(st, ranges):
+def allreduce_grads(st, ranges, scale_fn=None):
     """Data-parallel gradient exchange (new vs. the single-device reference): ONE RCCL all-reduce
-    per active contiguous gradient range, averaged over ranks; no-op when torch.distributed is not initialised."""
+    per active contiguous gradient range (generator phase: ~17.05 M floats, D phase: 0.28 M), summed then scaled by
+    1/world with a HIP kernel; no-op when torch.distributed is not initialised.  `scale_fn` exists so the exchange
+    logic can be exercised by the world_size-2 gloo test on CPU tensors."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return
+        return 0
     ws = dist.get_world_size()
+    scale_fn = scale_fn or ops.scale_inplace
+    n = 0
     for a, b in ranges:
         buf = st.grad[a:b]
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        ops.scale_inplace(buf, 1.0 / ws)
+        scale_fn(buf, 1.0 / ws)
+        n += 1
+    return n
 
 
 def initialize_model(args):
