@@ -32,7 +32,9 @@ const char* unast_arch(void);
  * a_mode/b_mode: 0 K-contiguous, 1 K-contiguous conv gather (A only), 2 row-contiguous,
  *                3 conv-dgrad weights (B only), 4 conv-wgrad gather (B only).
  * Epilogue: x = alpha*acc (+bias[n]) -> relu if act==1 -> dropout(drop_p) -> gate (G>0 ? x*gate_scale : 0)
- *           -> + R[m,n] -> (+C if beta) ; split-K (splitk>1) accumulates into C with fp32 atomics. */
+ *           -> + R[m,n] -> (+C if beta).  split-K (splitk>1, plain alpha/beta epilogue only): partial sums go to
+ *           splitk_ws ([splitk][M][ceil4(N)] floats, caller-owned) and a second launch reduces them into C; with
+ *           splitk_ws == NULL the partials are added to C with fp32 atomics (needs beta=1). */
 int unast_gemm(int a_mode, int b_mode, int nsplit,
                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                int M, int N, int K,
@@ -40,7 +42,7 @@ int unast_gemm(int a_mode, int b_mode, int nsplit,
                const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale,
                float alpha, int beta, int act,
                float drop_p, unsigned int seed, unsigned int stream_id,
-               int splitk, hipStream_t stream);
+               int splitk, float* splitk_ws, int64_t splitk_ws_floats, hipStream_t stream);
 
 /* Fused multi-head attention core (head_dim 64), flash-style.  Replaces the softmax(QK^T/sqrt(d)+mask) -> dropout -> V
  * core of torch.nn.MultiheadAttention inside torch.nn.TransformerEncoderLayer/DecoderLayer

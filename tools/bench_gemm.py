@@ -12,16 +12,16 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-def wgrad(M, N, K, sk):
+def wgrad(M, N, K, sk, atomic=False):
     dy = torch.randn(K, M, device=D); x = torch.randn(K, N, device=D); dW = torch.zeros(M, N, device=D)
-    return timeit(lambda: ops.gemm(ops.OP_RC, ops.OP_RC, dy, M, x, N, dW, N, M, N, K, beta=1, splitk=sk))
+    return timeit(lambda: ops.gemm(ops.OP_RC, ops.OP_RC, dy, M, x, N, dW, N, M, N, K, beta=1, splitk=sk, atomic=atomic))
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "wgrad"
     if which == "wgrad":
         for (M, N, K) in [(256, 256, 25600), (256, 1024, 25600), (1024, 256, 25600), (768, 256, 25600), (256, 256, 5760), (1024, 256, 5760), (256, 1280, 25600), (512, 256, 51200)]:
             row = []
-            for sk in (4, 8, 16, 32, 64, 128, 256):
+            for sk in (8, 16, 32, 64, 100, 128, 200):
                 us = wgrad(M, N, K, sk)
                 row.append("sk%d:%.0fus(%.0fTF)" % (sk, us, 2.0 * M * N * K / us / 1e6))
             print((M, N, K), " ".join(row), flush=True)

@@ -33,6 +33,7 @@ struct GemmParams {
     float alpha; int beta; int act;
     uint32_t drop_thresh; float drop_scale; uint32_t seed, stream;
     int kchunk; int atomic; int tiles_m, tiles_n;
+    float* slab; int ld_slab; size_t slab_stride;     // split-K partial slabs [z][M][ld_slab]
 };
 
 __device__ __forceinline__ int swz_h(int row) { return (0x1320 >> (((row >> 2) & 3) << 2)) & 3; }
@@ -96,22 +97,27 @@ __device__ __forceinline__ float4 load_rc(const GemmParams& p, const float* __re
 }
 
 template <int AM, int BMODE, int NSPLIT>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     constexpr bool A_KC = (AM == OP_KC || AM == OP_KC_CONV);
     constexpr bool B_KC = (BMODE == OP_KC);
     constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
     constexpr int A_BYTES = A_KC ? KC_BYTES : RC_BYTES;
     constexpr int B_BYTES = B_KC ? KC_BYTES : RC_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(A_BYTES + B_BYTES) * PARTS];
-    unsigned char* sA = smem;
-    unsigned char* sB = smem + A_BYTES * PARTS;
+    constexpr int STAGE = (A_BYTES + B_BYTES) * PARTS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];      // two stages: one barrier per k-step
 
     // XCD-aware tile mapping: blocks b and b+8 (same XCD under round-robin dispatch) share the A row panel.
     const int pid = blockIdx.x;
-    const int G = 8 * p.tiles_n;
-    const int grp = pid / G, rem = pid - grp * G;
-    const int tile_m = grp * 8 + (rem & 7);
-    const int tile_n = rem >> 3;
+    int tile_m, tile_n;
+    if (p.tiles_m >= 8) {
+        const int G = 8 * p.tiles_n;
+        const int grp = pid / G, rem = pid - grp * G;
+        tile_m = grp * 8 + (rem & 7);
+        tile_n = rem >> 3;
+    } else {                                // few row panels (weight gradients): plain map, every XCD gets work
+        tile_m = pid % p.tiles_m;
+        tile_n = pid / p.tiles_m;
+    }
     if (tile_m >= p.tiles_m) return;        // whole block exits together (keeps EXEC full for tr reads)
     const int m0 = tile_m * GBM, n0 = tile_n * GBN;
     const int kbeg = blockIdx.y * p.kchunk;
@@ -141,8 +147,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         b_cc = row - b_cj * p.cb;
     }
 
-    float4 ra[4], rb[4];
-    auto load_tiles = [&](int kt) {
+    auto load_tiles = [&](int kt, float4 (&ra)[4], float4 (&rb)[4]) {
         const int k0 = kbeg + kt * GBK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
             else      rb[i] = load_rc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t & 31) * 4, k0 + (t >> 5) + 8 * i, kend, b_cj, b_cc);
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](const float4 (&ra)[4], const float4 (&rb)[4], unsigned char* sA, unsigned char* sB) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x2 hi, lo;
@@ -186,11 +191,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (nk > 0) load_tiles(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        store_tiles();
-        __syncthreads();
-        if (kt + 1 < nk) load_tiles(kt + 1);
+    auto compute = [&](const unsigned char* sA, const unsigned char* sB) {
         bf16x8_t af[4][PARTS], bfr[4][PARTS];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -210,12 +211,58 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                 }
                 acc[i][j] = mfma16(bfr[j][0], af[i][0], acc[i][j]);
             }
+    };
+
+    // Two register sets keep tiles kt+1 and kt+2 in flight while tile kt is multiplied; two LDS stages need a single
+    // barrier per k-step (a stage is rewritten only after every wave has passed the barrier that follows its last read).
+    float4 ra0[4], rb0[4], ra1[4], rb1[4];
+    unsigned char* const s0A = smem;
+    unsigned char* const s0B = smem + A_BYTES * PARTS;
+    unsigned char* const s1A = smem + STAGE;
+    unsigned char* const s1B = smem + STAGE + A_BYTES * PARTS;
+    if (nk > 0) load_tiles(0, ra0, rb0);
+    if (nk > 1) load_tiles(1, ra1, rb1);
+    for (int kt = 0; kt < nk; kt += 2) {
+        store_tiles(ra0, rb0, s0A, s0B);
         __syncthreads();
+        if (kt + 2 < nk) load_tiles(kt + 2, ra0, rb0);
+        compute(s0A, s0B);
+        if (kt + 1 < nk) {
+            store_tiles(ra1, rb1, s1A, s1B);
+            __syncthreads();
+            if (kt + 3 < nk) load_tiles(kt + 3, ra1, rb1);
+            compute(s1A, s1B);
+        }
     }
 
     // ---- epilogue: lane holds C[m = ..+l15][n = ..+4g .. 4g+3] --------------------------------------
     const bool first_split = (blockIdx.y == 0);
-    const bool vec_ok = ((p.ldc & 3) == 0);
+    if (p.slab) {                                   // split-K: raw partial sums to this split's slab (plain 16-B stores)
+        float* slab = p.slab + (size_t)blockIdx.y * p.slab_stride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + 4 * g;
+                if (n >= p.N) continue;
+                *reinterpret_cast<float4*>(slab + (size_t)m * p.ld_slab + n) =
+                    make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+            }
+        }
+        return;
+    }
+    const bool vec_c = ((p.ldc & 3) == 0);
+    const bool vec_r = p.R && ((p.ldr & 3) == 0) && ((((uintptr_t)p.R) & 15) == 0);
+    const bool vec_g = p.G && ((p.ldg & 3) == 0) && ((((uintptr_t)p.G) & 15) == 0);
+    float bias_v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias_v[j][r] = (p.bias && first_split && n + r < p.N) ? p.bias[n + r] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + l15;
@@ -226,25 +273,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + 4 * g;
             if (n >= p.N) continue;
+            const bool full = (n + 3 < p.N);
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            float gv[4] = {1.f, 1.f, 1.f, 1.f}, rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.G) {
+                if (vec_g && full) { float4 t4 = *reinterpret_cast<const float4*>(p.G + (size_t)m * p.ldg + n); gv[0] = t4.x; gv[1] = t4.y; gv[2] = t4.z; gv[3] = t4.w; }
+                else { for (int r = 0; r < 4; ++r) if (n + r < p.N) gv[r] = p.G[(size_t)m * p.ldg + n + r]; }
+            }
+            if (p.R && first_split) {
+                if (vec_r && full) { float4 t4 = *reinterpret_cast<const float4*>(p.R + (size_t)m * p.ldr + n); rv[0] = t4.x; rv[1] = t4.y; rv[2] = t4.z; rv[3] = t4.w; }
+                else { for (int r = 0; r < 4; ++r) if (n + r < p.N) rv[r] = p.R[(size_t)m * p.ldr + n + r]; }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int nn = n + r;
-                if (nn >= p.N) break;
-                float x = v[r] * p.alpha;
-                if (p.bias && first_split) x += p.bias[nn];
+                float x = v[r] * p.alpha + bias_v[j][r];
                 if (p.act == 1) x = fmaxf(x, 0.f);
-                if (p.drop_thresh) x = rng_keep(rkey, (uint32_t)nn, p.drop_thresh) ? x * p.drop_scale : 0.f;
-                if (p.G) x = (p.G[(size_t)m * p.ldg + nn] > 0.f) ? x * p.gate_scale : 0.f;
-                if (p.R && first_split) x += p.R[(size_t)m * p.ldr + nn];
-                v[r] = x;
+                if (p.drop_thresh) x = rng_keep(rkey, (uint32_t)(n + r), p.drop_thresh) ? x * p.drop_scale : 0.f;
+                if (p.G) x = (gv[r] > 0.f) ? x * p.gate_scale : 0.f;
+                v[r] = x + rv[r];
             }
             float* cp = p.C + (size_t)m * p.ldc + n;
             if (p.atomic) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (n + r < p.N) atomicAdd(cp + r, v[r]);
-            } else if (vec_ok && n + 3 < p.N) {
+            } else if (vec_c && full) {
                 float4 o = make_float4(v[0], v[1], v[2], v[3]);
                 if (p.beta) {
                     float4 c = *reinterpret_cast<const float4*>(cp);
@@ -257,6 +310,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                     if (n + r < p.N) cp[r] = p.beta ? cp[r] + v[r] : v[r];
             }
         }
+    }
+}
+
+// C[m][n] (+)= sum_z slab[z][m][n]: reduction of the split-K partial slabs (plain streaming reads, deterministic order).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, size_t slab_stride, int ld_slab, int nsplit,
+                                                            float* __restrict__ C, int ldc, int M, int N, int beta) {
+    const int nq = ld_slab >> 2;
+    const size_t total = (size_t)M * nq;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / nq), n = (int)(i - (size_t)m * nq) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* sp = slab + (size_t)m * ld_slab + n;
+        for (int z = 0; z < nsplit; ++z) {
+            float4 v = *reinterpret_cast<const float4*>(sp + (size_t)z * slab_stride);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        float* cp = C + (size_t)m * ldc + n;
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < N) cp[r] = beta ? cp[r] + av[r] : av[r];
     }
 }
 
@@ -278,15 +352,16 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
                           const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale,
                           float alpha, int beta, int act,
                           float drop_p, unsigned int seed, unsigned int stream_id,
-                          int splitk, hipStream_t stream) {
+                          int splitk, float* splitk_ws, int64_t splitk_ws_floats, hipStream_t stream) {
     UNAST_REQUIRE(A && B && C, "unast_gemm: null operand");
     UNAST_REQUIRE(M > 0 && N > 0 && K > 0, "unast_gemm: bad dims M=%d N=%d K=%d", M, N, K);
     UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_gemm: nsplit must be 1 or 3");
     UNAST_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C), "unast_gemm: operands must be 16-byte aligned");
     UNAST_REQUIRE((lda & 3) == 0 && (ldb & 3) == 0, "unast_gemm: lda/ldb must be multiples of 4 (got %d, %d)", lda, ldb);
     UNAST_REQUIRE(splitk >= 1, "unast_gemm: splitk >= 1");
-    UNAST_REQUIRE(!(splitk > 1 && (act || drop_p > 0.f || G || beta == 0)),
-                  "unast_gemm: split-K accumulates atomically into C (beta=1) and allows only bias/residual epilogues");
+    UNAST_REQUIRE(!(splitk > 1 && (act || drop_p > 0.f || G || bias || R)),
+                  "unast_gemm: split-K supports only the plain alpha/beta epilogue");
+    UNAST_REQUIRE(!(splitk > 1 && !splitk_ws && beta == 0), "unast_gemm: atomic split-K (no workspace) accumulates into C: needs beta=1");
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.T = conv_T > 0 ? conv_T : 1; p.ca = conv_ca > 0 ? conv_ca : 1; p.cb = conv_cb > 0 ? conv_cb : 1;
@@ -301,11 +376,23 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     int steps_per = (ksteps + splitk - 1) / splitk;
     p.kchunk = steps_per * GBK;
     splitk = (ksteps + steps_per - 1) / steps_per;
-    p.atomic = splitk > 1 ? 1 : 0;
+    p.slab = nullptr; p.ld_slab = 0; p.slab_stride = 0;
+    p.atomic = 0;
+    if (splitk > 1) {
+        if (splitk_ws) {
+            p.ld_slab = (N + 3) & ~3;
+            p.slab_stride = (size_t)M * p.ld_slab;
+            UNAST_REQUIRE((int64_t)(p.slab_stride * splitk) <= splitk_ws_floats && ((((uintptr_t)splitk_ws) & 15) == 0),
+                          "unast_gemm: split-K workspace too small (need %lld floats) or misaligned", (long long)(p.slab_stride * splitk));
+            p.slab = splitk_ws;
+        } else {
+            p.atomic = 1;
+        }
+    }
     if (a_mode == OP_KC_CONV) UNAST_REQUIRE((conv_ca & 3) == 0 && K == 5 * conv_ca && M % p.T == 0, "unast_gemm: bad conv A geometry");
     if (b_mode == OP_RC_CONV_DGRAD) UNAST_REQUIRE(K == 5 * conv_cb, "unast_gemm: bad conv dgrad geometry");
     if (b_mode == OP_RC_CONV_WGRAD) UNAST_REQUIRE((conv_cb & 3) == 0 && N == 5 * conv_cb && K % p.T == 0, "unast_gemm: bad conv wgrad geometry");
-    dim3 grid(((p.tiles_m + 7) / 8) * 8 * p.tiles_n, splitk, 1);
+    dim3 grid(p.tiles_m >= 8 ? ((p.tiles_m + 7) / 8) * 8 * p.tiles_n : p.tiles_m * p.tiles_n, splitk, 1);
     if (a_mode == OP_KC && b_mode == OP_KC) launch_split<OP_KC, OP_KC>(p, nsplit, grid, stream);
     else if (a_mode == OP_KC && b_mode == OP_RC) launch_split<OP_KC, OP_RC>(p, nsplit, grid, stream);
     else if (a_mode == OP_RC && b_mode == OP_RC) launch_split<OP_RC, OP_RC>(p, nsplit, grid, stream);
@@ -313,5 +400,11 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     else if (a_mode == OP_KC_CONV && b_mode == OP_RC_CONV_DGRAD) launch_split<OP_KC_CONV, OP_RC_CONV_DGRAD>(p, nsplit, grid, stream);
     else if (a_mode == OP_RC && b_mode == OP_RC_CONV_WGRAD) launch_split<OP_RC, OP_RC_CONV_WGRAD>(p, nsplit, grid, stream);
     else return unast_set_error(UNAST_ERR_ARG, "unast_gemm: unsupported operand mode pair (%d,%d)", a_mode, b_mode);
+    if (p.slab) {
+        size_t work = (size_t)M * (p.ld_slab / 4);
+        size_t blocks = (work + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p.slab, p.slab_stride, p.ld_slab, splitk, C, ldc, M, N, beta);
+    }
     return unast_check_launch("unast_gemm");
 }

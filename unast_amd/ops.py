@@ -27,18 +27,29 @@ def _f32(t, name):
 
 
 def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bias=None, R=None, ldr=0, G=None,
-         ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None):
+         ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False):
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (R, "R"), (G, "G")):
         _f32(t, n)
+    ws, ws_n = None, 0
+    if splitk > 1 and not atomic:
+        ws_n = splitk * M * ((N + 3) // 4 * 4)
+        ws = torch.empty(ws_n, dtype=torch.float32, device=C.device)          # split-K partial slabs (caching allocator)
     check(lib().unast_gemm(a_mode, b_mode, nsplit or config.NSPLIT, _p(A), lda, _p(B), ldb, _p(C), ldc, M, N, K,
                            conv[0], conv[1], conv[2], conv[3], _p(bias), _p(R), ldr, _p(G), ldg, gate_scale,
-                           alpha, beta, act, drop_p, seed & 0xFFFFFFFF, stream_id, splitk, _stream()), "unast_gemm")
+                           alpha, beta, act, drop_p, seed & 0xFFFFFFFF, stream_id, splitk, _p(ws), ws_n, _stream()), "unast_gemm")
+
+
+SPLITK_TARGET_BLOCKS = 320
+SPLITK_MIN_KSTEPS = 10
 
 
 def _splitk_for(M, N, K):
+    """Split the long token reduction of a weight gradient so that ~SPLITK_TARGET_BLOCKS workgroups are in flight, each
+    with at least SPLITK_MIN_KSTEPS 32-deep k-steps."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    want = max(1, 768 // tiles)
-    return max(1, min(want, K // 128 if K >= 128 else 1))
+    ksteps = (K + 31) // 32
+    want = max(1, SPLITK_TARGET_BLOCKS // tiles)
+    return max(1, min(want, ksteps // SPLITK_MIN_KSTEPS))
 
 
 def linear_fwd(x2d, W, bias, out, act=0, drop_p=0.0, seed=0, stream_id=0, R=None):
