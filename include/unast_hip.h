@@ -34,7 +34,9 @@ const char* unast_arch(void);
  * Epilogue: x = alpha*acc (+bias[n]) -> relu if act==1 -> dropout(drop_p) -> gate (G>0 ? x*gate_scale : 0)
  *           -> + R[m,n] -> (+C if beta).  split-K (splitk>1, plain alpha/beta epilogue only): partial sums go to
  *           splitk_ws ([splitk][M][ceil4(N)] floats, caller-owned) and a second launch reduces them into C; with
- *           splitk_ws == NULL the partials are added to C with fp32 atomics (needs beta=1). */
+ *           splitk_ws == NULL the partials are added to C with fp32 atomics (needs beta=1).
+ * rowsum_a (a_mode 2 only, may be NULL): rowsum_a[m] += sum_k A[m][k] — the bias gradient sum_tokens dY fused into
+ *           the weight-gradient pass that already streams dY. */
 int unast_gemm(int a_mode, int b_mode, int nsplit,
                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                int M, int N, int K,
@@ -42,7 +44,7 @@ int unast_gemm(int a_mode, int b_mode, int nsplit,
                const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale,
                float alpha, int beta, int act,
                float drop_p, unsigned int seed, unsigned int stream_id,
-               int splitk, float* splitk_ws, int64_t splitk_ws_floats, hipStream_t stream);
+               int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, hipStream_t stream);
 
 /* Fused multi-head attention core (head_dim 64), flash-style.  Replaces the softmax(QK^T/sqrt(d)+mask) -> dropout -> V
  * core of torch.nn.MultiheadAttention inside torch.nn.TransformerEncoderLayer/DecoderLayer
@@ -60,12 +62,15 @@ int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* K, int ldk,
 
 /* LayerNorm(eps) of the post-LN transformer blocks (norm1/2/3 inside torch layers, src/module.py:273-274,286-287).
  * bwd: dz (and optionally dz_drop = dz * dropout mask/(1-p), the gradient of the dropped sub-layer output);
- * dgamma/dbeta are ACCUMULATED (+=) and may be NULL for frozen parameters. */
+ * dgamma/dbeta are ACCUMULATED (+=) and may be NULL for frozen parameters (then ws may be NULL too). */
 int unast_layernorm_fwd(const float* z, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int rows, int C, float eps, hipStream_t stream);
 int unast_layernorm_bwd(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd,
-                        float* dz, float* dz_drop, float* dgamma, float* dbeta, int rows, int C,
+                        float* dz, float* dz_drop, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, int rows, int C,
                         float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);
+/* floats of `ws` unast_layernorm_bwd needs for (rows, C): per-workgroup column partials, reduced by a second launch
+ * (no same-address atomics). */
+int64_t unast_layernorm_bwd_ws_floats(int rows, int C);
 
 /* Column sums sum[c] += sum_r x[r,c] (bias gradients of every nn.Linear/nn.Conv1d on the path). */
 int unast_colsum_f32(const float* x, int ldx, int rows, int C, float* sum, hipStream_t stream);

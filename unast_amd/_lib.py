@@ -39,9 +39,9 @@ def parse_header(path=HEADER_PATH):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
     protos = {}
-    for m in re.finditer(r"(const\s+char\s*\*|int|void)\s+(unast_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"(const\s+char\s*\*|int64_t|int|void)\s+(unast_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
-        restype = ctypes.c_char_p if "char" in ret else (None if ret == "void" else ctypes.c_int)
+        restype = ctypes.c_char_p if "char" in ret else (None if ret == "void" else (ctypes.c_longlong if ret == "int64_t" else ctypes.c_int))
         argtypes = [] if args in ("", "void") else [_ctype(a) for a in args.split(",")]
         protos[name] = (restype, argtypes)
     _protos = protos

@@ -40,26 +40,38 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
     }
 }
 
-// Embedding backward: one block per vocabulary row (deterministic, no atomics).  Row `padding_idx` gets no gradient.
+// Embedding backward: grid (vocab, token chunks); a workgroup scans its chunk, sums the rows that hit its vocabulary id
+// in registers (thread = column) and adds them with one atomic per column.  Row `padding_idx` gets no gradient.
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
                                                         float* __restrict__ dE, int rows, int T, int D, int shift_sos, int padding_idx,
-                                                        uint32_t drop_thresh, float drop_scale, uint32_t seed, uint32_t stream,
+                                                        int rows_per_chunk, uint32_t drop_thresh, float drop_scale, uint32_t seed, uint32_t stream,
                                                         uint32_t noise_thresh, uint32_t noise_stream) {
+    __shared__ int hit[512];
+    __shared__ int nhit;
     const int v = blockIdx.x;
     if (v == padding_idx) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    if (threadIdx.x == 0) nhit = 0;
+    __syncthreads();
+    for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+        int64_t id;
+        if (shift_sos >= 0) { const int t = r % T; id = (t == 0) ? (int64_t)shift_sos : ids[r - 1]; }
+        else id = ids[r];
+        if (id == v) { const int k = atomicAdd(&nhit, 1); if (k < 512) hit[k] = r; }
+    }
+    __syncthreads();
+    const int n = min(nhit, 512);
+    if (n == 0) return;
     for (int c = threadIdx.x; c < D; c += 256) {
         float acc = 0.f;
-        for (int r = 0; r < rows; ++r) {
-            int64_t id;
-            if (shift_sos >= 0) { const int t = r % T; id = (t == 0) ? (int64_t)shift_sos : ids[r - 1]; }
-            else id = ids[r];
-            if (id != v) continue;
+        for (int k = 0; k < n; ++k) {
+            const int r = hit[k];
             float g = dout[(size_t)r * D + c];
             if (drop_thresh) g = rng_keep(rng_row_key(seed, stream, (uint32_t)r), c, drop_thresh) ? g * drop_scale : 0.f;
             if (noise_thresh && !rng_keep(rng_row_key(seed, noise_stream, (uint32_t)r), 0u, noise_thresh)) g = 0.f;
             acc += g;
         }
-        dE[(size_t)v * D + c] += acc;
+        atomicAdd(dE + (size_t)v * D + c, acc);
     }
 }
 
@@ -241,7 +253,8 @@ extern "C" int unast_embed_bwd(const int64_t* ids, const float* dout, float* dE,
                                int padding_idx, float drop_p, unsigned int seed, unsigned int stream_id, float noise_p,
                                unsigned int noise_stream, hipStream_t stream) {
     UNAST_REQUIRE(ids && dout && dE && rows > 0 && T > 0 && vocab > 0, "unast_embed_bwd: bad arguments");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(vocab), dim3(256), 0, stream, ids, dout, dE, rows, T, D, shift_sos, padding_idx,
+    const int rpc = 256;                       // <= 512 hits per (vocab row, chunk) by construction
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(vocab, (rows + rpc - 1) / rpc), dim3(256), 0, stream, ids, dout, dE, rows, T, D, shift_sos, padding_idx, rpc,
                        drop_threshold(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, stream_id, drop_threshold(noise_p), noise_stream);
     return unast_check_launch("unast_embed_bwd");
 }

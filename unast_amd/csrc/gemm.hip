@@ -34,6 +34,7 @@ struct GemmParams {
     uint32_t drop_thresh; float drop_scale; uint32_t seed, stream;
     int kchunk; int atomic; int tiles_m, tiles_n;
     float* slab; int ld_slab; size_t slab_stride;     // split-K partial slabs [z][M][ld_slab]
+    float* rowsum_a;                                  // optional: rowsum_a[m] += sum_k A[m][k] (bias gradient fused into wgrad)
 };
 
 __device__ __forceinline__ int swz_h(int row) { return (0x1320 >> (((row >> 2) & 3) << 2)) & 3; }
@@ -157,10 +158,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             else      rb[i] = load_rc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t & 31) * 4, k0 + (t >> 5) + 8 * i, kend, b_cj, b_cc);
         }
     };
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = (AM == OP_RC) && p.rowsum_a && tile_n == 0;
     auto store_tiles = [&](const float4 (&ra)[4], const float4 (&rb)[4], unsigned char* sA, unsigned char* sB) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x2 hi, lo;
+            if (AM == OP_RC && do_rowsum) { bsum[0] += ra[i].x; bsum[1] += ra[i].y; bsum[2] += ra[i].z; bsum[3] += ra[i].w; }
             split4<NSPLIT>(ra[i], hi, lo);
             int off = A_KC ? kc_off((t >> 3) + 32 * i, (t & 7) * 4) : (((t >> 5) + 8 * i) * RC_STRIDE + (t & 31) * 4) * 2;
             *reinterpret_cast<u32x2*>(sA + off) = hi;
@@ -235,6 +239,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         }
     }
 
+    if (AM == OP_RC && do_rowsum) {          // threads t, t+32, ... hold partial sums of rows m0 + 4*(t&31) .. +3
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (t < 128) red[t] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) atomicAdd(&red[(t & 31) * 4 + c], bsum[c]);
+        __syncthreads();
+        if (t < 128 && m0 + t < p.M) atomicAdd(p.rowsum_a + m0 + t, red[t]);
+    }
     // ---- epilogue: lane holds C[m = ..+l15][n = ..+4g .. 4g+3] --------------------------------------
     const bool first_split = (blockIdx.y == 0);
     if (p.slab) {                                   // split-K: raw partial sums to this split's slab (plain 16-B stores)
@@ -352,7 +366,7 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
                           const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale,
                           float alpha, int beta, int act,
                           float drop_p, unsigned int seed, unsigned int stream_id,
-                          int splitk, float* splitk_ws, int64_t splitk_ws_floats, hipStream_t stream) {
+                          int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, hipStream_t stream) {
     UNAST_REQUIRE(A && B && C, "unast_gemm: null operand");
     UNAST_REQUIRE(M > 0 && N > 0 && K > 0, "unast_gemm: bad dims M=%d N=%d K=%d", M, N, K);
     UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_gemm: nsplit must be 1 or 3");
@@ -377,6 +391,8 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     p.kchunk = steps_per * GBK;
     splitk = (ksteps + steps_per - 1) / steps_per;
     p.slab = nullptr; p.ld_slab = 0; p.slab_stride = 0;
+    p.rowsum_a = rowsum_a;
+    UNAST_REQUIRE(!rowsum_a || a_mode == OP_RC, "unast_gemm: rowsum_a needs a row-contiguous A operand (weight-gradient form)");
     p.atomic = 0;
     if (splitk > 1) {
         if (splitk_ws) {

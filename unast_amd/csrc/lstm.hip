@@ -11,17 +11,28 @@
 #define LH 64             // hidden size
 #define LG (4 * LH)       // gate rows
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
+
+#define FCH 16            // forward: timesteps of input projections held in registers per chunk
+#define BCH 8             // backward: timesteps of saved state held in registers per chunk
 
 // xproj [Bd,T,ndir*LG] (no bias), y [Bd,T,ndir*LH] (pre-zeroed), gates [Bd,T,ndir,LG], cs [Bd,T,ndir,LH],
 // hprev [Bd,T,ndir,LH] (pre-zeroed), hfinal [Bd, ndir*LH]
+//
+// One barrier per timestep: thread j (wave w = j>>6 owns gate type i/f/g/o) computes its gate pre-activation from the
+// wave-private copy of h, publishes the activated gate in a double-buffered LDS array, and after the barrier EVERY wave
+// redundantly performs the cell update of hidden unit j&63 and refreshes its private h copy (no second barrier).
+// Global latency is taken off the per-step critical path: each thread keeps the projections of the current chunk of
+// FCH steps in registers while the next chunk's loads are in flight (one vmcnt wait per chunk, not per step).
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ xproj, const float* __restrict__ whh, const float* __restrict__ b_ih,
                                                        const float* __restrict__ b_hh, const int* __restrict__ lens, float* __restrict__ y,
                                                        float* __restrict__ gates, float* __restrict__ cs, float* __restrict__ hprev,
                                                        float* __restrict__ hfinal, int T, int ndir, size_t whh_dir_stride, size_t bias_dir_stride) {
-    __shared__ __attribute__((aligned(16))) float h_lds[LH];
-    __shared__ float g_lds[LG];
+    __shared__ __attribute__((aligned(16))) float h_lds[4][LH];       // one private copy per wave
+    __shared__ float g_lds[2][LG];
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
+    const int wave = j >> 6, u = j & 63;
     const int len = lens[b];
     float w[LH];
     const float* wr = whh + dir * whh_dir_stride + (size_t)j * LH;
@@ -31,50 +42,68 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
         w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
     }
     const float bias = b_ih[dir * bias_dir_stride + j] + b_hh[dir * bias_dir_stride + j];
-    if (j < LH) h_lds[j] = 0.f;
+    h_lds[wave][u] = 0.f;
     float c = 0.f, h = 0.f;
     const size_t xs = (size_t)ndir * LG;
     const float* xp = xproj + (size_t)b * T * xs + (size_t)dir * LG + j;
-    __syncthreads();
-    float xg = (len > 0) ? xp[(size_t)(dir ? len - 1 : 0) * xs] : 0.f;
-    for (int step = 0; step < len; ++step) {
-        const int t = dir ? (len - 1 - step) : step;
-        float xn = 0.f;
-        if (step + 1 < len) xn = xp[(size_t)(dir ? t - 1 : t + 1) * xs];     // prefetch next step's projection
-        float a0 = xg + bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int tstep = dir ? -1 : 1;
+    const int t0 = dir ? len - 1 : 0;
+    float xc[FCH], xn[FCH];
+    auto load_chunk = [&](int s0, float (&x)[FCH]) {
 #pragma unroll
-        for (int k = 0; k < LH; k += 4) {
-            float4 hv = *reinterpret_cast<const float4*>(&h_lds[k]);
-            a0 = fmaf(w[k], hv.x, a0); a1 = fmaf(w[k + 1], hv.y, a1); a2 = fmaf(w[k + 2], hv.z, a2); a3 = fmaf(w[k + 3], hv.w, a3);
+        for (int i = 0; i < FCH; ++i) {
+            const int st = min(s0 + i, len - 1);                   // clamped: a fixed number of loads per chunk
+            x[i] = xp[(size_t)(t0 + st * tstep) * xs];
         }
-        const float pre = (a0 + a1) + (a2 + a3);
-        const float act = ((j >> 6) == 2) ? tanhf(pre) : sigmoidf_(pre);      // wave-uniform: waves = i,f,g,o
-        g_lds[j] = act;
-        const size_t row = ((size_t)b * T + t) * ndir + dir;
-        gates[row * LG + j] = act;
-        __syncthreads();
-        if (j < LH) {
-            const float ig = g_lds[j], fg = g_lds[LH + j], gg = g_lds[2 * LH + j], og = g_lds[3 * LH + j];
-            hprev[row * LH + j] = h;
+    };
+    if (len > 0) load_chunk(0, xn);
+    for (int s0 = 0; s0 < len; s0 += FCH) {
+#pragma unroll
+        for (int i = 0; i < FCH; ++i) xc[i] = xn[i];                // the only wait for global loads: once per chunk
+        if (s0 + FCH < len) load_chunk(s0 + FCH, xn);
+#pragma unroll
+        for (int i = 0; i < FCH; ++i) {
+            const int step = s0 + i;
+            if (step >= len) break;
+            const int t = t0 + step * tstep;
+            float a0 = xc[i] + bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int k = 0; k < LH; k += 4) {
+                float4 hv = *reinterpret_cast<const float4*>(&h_lds[wave][k]);
+                a0 = fmaf(w[k], hv.x, a0); a1 = fmaf(w[k + 1], hv.y, a1); a2 = fmaf(w[k + 2], hv.z, a2); a3 = fmaf(w[k + 3], hv.w, a3);
+            }
+            const float pre = (a0 + a1) + (a2 + a3);
+            const float act = (wave == 2) ? tanhf_(pre) : sigmoidf_(pre);        // wave-uniform: waves = i,f,g,o
+            float* gl = g_lds[i & 1];
+            gl[j] = act;
+            const size_t row = ((size_t)b * T + t) * ndir + dir;
+            gates[row * LG + j] = act;
+            __syncthreads();
+            const float ig = gl[u], fg = gl[LH + u], gg = gl[2 * LH + u], og = gl[3 * LH + u];
+            if (wave == 0) hprev[row * LH + u] = h;
             c = fg * c + ig * gg;
-            h = og * tanhf(c);
-            cs[row * LH + j] = c;
-            y[((size_t)b * T + t) * (ndir * LH) + dir * LH + j] = h;
-            h_lds[j] = h;
+            h = og * tanhf_(c);
+            if (wave == 0) {
+                cs[row * LH + u] = c;
+                y[((size_t)b * T + t) * (ndir * LH) + dir * LH + u] = h;
+            }
+            h_lds[wave][u] = h;           // same-wave LDS write -> read ordering: no barrier needed
         }
-        __syncthreads();
-        xg = xn;
     }
-    if (j < LH) hfinal[(size_t)b * (ndir * LH) + dir * LH + j] = h;
+    if (wave == 0) hfinal[(size_t)b * (ndir * LH) + dir * LH + u] = h;
 }
 
 // Backward through time.  dy [Bd,T,ndir*LH] (may be null), dhfinal [Bd,ndir*LH] (may be null),
 // dgates [Bd,T,ndir,LG] (pre-zeroed; receives d(pre-activation gates) for valid steps).
+// One barrier per step: every wave redundantly forms the four gate gradients of unit k = lane (from the shared dh),
+// keeps them in a wave-private LDS copy, computes its quarter (gate rows 64*wave..) of dh_prev = dg . W_hh, and after
+// the barrier every wave sums the four partials.  Saved gates / cell states / dy of BCH steps are register-resident
+// while the next chunk's loads are in flight.
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dhfinal, const float* __restrict__ whh,
                                                        const float* __restrict__ gates, const float* __restrict__ cs, const int* __restrict__ lens,
                                                        float* __restrict__ dgates, int T, int ndir, size_t whh_dir_stride) {
-    __shared__ __attribute__((aligned(16))) float dg_lds[LG];
-    __shared__ float part_lds[4][LH];
+    __shared__ __attribute__((aligned(16))) float dg_lds[4][LG];      // wave-private copies
+    __shared__ float part_lds[2][4][LH];
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
     const int len = lens[b];
     const int k = j & 63, part = j >> 6;
@@ -83,41 +112,63 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < LH; ++i) wt[i] = wr[(size_t)i * LH];
     float dh = 0.f, dc = 0.f;
-    if (j < LH && dhfinal) dh = dhfinal[(size_t)b * (ndir * LH) + dir * LH + j];
-    for (int step = len - 1; step >= 0; --step) {           // reverse of the forward processing order
-        const int t = dir ? (len - 1 - step) : step;
-        const size_t row = ((size_t)b * T + t) * ndir + dir;
-        if (j < LH) {
-            float dht = dh;
-            if (dy) dht += dy[((size_t)b * T + t) * (ndir * LH) + dir * LH + j];
-            const float ig = gates[row * LG + j], fg = gates[row * LG + LH + j], gg = gates[row * LG + 2 * LH + j], og = gates[row * LG + 3 * LH + j];
-            const float ct = cs[row * LH + j];
-            float cprev = 0.f;
-            if (step > 0) {
-                const int tp = dir ? t + 1 : t - 1;
-                cprev = cs[(((size_t)b * T + tp) * ndir + dir) * LH + j];
-            }
-            const float tc = tanhf(ct);
+    if (dhfinal) dh = dhfinal[(size_t)b * (ndir * LH) + dir * LH + k];
+    const int tstep = dir ? 1 : -1;                         // reverse of the forward processing order
+    const int t0 = dir ? 0 : len - 1;
+    // r = 0..len-1 counts backward steps; forward step index = len-1-r; time t = t0 + r*tstep
+    float vc[BCH][7], vn[BCH][7];
+    auto load_chunk = [&](int r0, float (&v)[BCH][7]) {
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int r = min(r0 + i, len - 1);
+            const int t = t0 + r * tstep;
+            const size_t row = ((size_t)b * T + t) * ndir + dir;
+            v[i][0] = gates[row * LG + k]; v[i][1] = gates[row * LG + LH + k]; v[i][2] = gates[row * LG + 2 * LH + k]; v[i][3] = gates[row * LG + 3 * LH + k];
+            v[i][4] = cs[row * LH + k];
+            const int rp = min(r + 1, len - 1);             // previous forward step (clamped; masked below for the first step)
+            v[i][5] = cs[(((size_t)b * T + (t0 + rp * tstep)) * ndir + dir) * LH + k];
+            v[i][6] = dy ? dy[((size_t)b * T + t) * (ndir * LH) + dir * LH + k] : 0.f;
+        }
+    };
+    if (len > 0) load_chunk(0, vn);
+    for (int r0 = 0; r0 < len; r0 += BCH) {
+#pragma unroll
+        for (int i = 0; i < BCH; ++i)
+#pragma unroll
+            for (int q = 0; q < 7; ++q) vc[i][q] = vn[i][q];
+        if (r0 + BCH < len) load_chunk(r0 + BCH, vn);
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int r = r0 + i;
+            if (r >= len) break;
+            const int t = t0 + r * tstep;
+            const float ig = vc[i][0], fg = vc[i][1], gg = vc[i][2], og = vc[i][3], ct = vc[i][4];
+            const float cprev = (r == len - 1) ? 0.f : vc[i][5];
+            const float dht = dh + vc[i][6];
+            const float tc = tanhf_(ct);
             const float d_o = dht * tc * og * (1.f - og);
             const float dct = dc + dht * og * (1.f - tc * tc);
             const float d_i = dct * gg * ig * (1.f - ig);
             const float d_f = dct * cprev * fg * (1.f - fg);
             const float d_g = dct * ig * (1.f - gg * gg);
             dc = dct * fg;
-            dg_lds[j] = d_i; dg_lds[LH + j] = d_f; dg_lds[2 * LH + j] = d_g; dg_lds[3 * LH + j] = d_o;
-            float* dgr = dgates + row * LG;
-            dgr[j] = d_i; dgr[LH + j] = d_f; dgr[2 * LH + j] = d_g; dgr[3 * LH + j] = d_o;
-        }
-        __syncthreads();
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            float* dgw = dg_lds[part];
+            dgw[k] = d_i; dgw[LH + k] = d_f; dgw[2 * LH + k] = d_g; dgw[3 * LH + k] = d_o;
+            if (part == 0) {
+                float* dgr = dgates + (((size_t)b * T + t) * ndir + dir) * LG;
+                dgr[k] = d_i; dgr[LH + k] = d_f; dgr[2 * LH + k] = d_g; dgr[3 * LH + k] = d_o;
+            }
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LH; i += 4) {
-            float4 dv = *reinterpret_cast<const float4*>(&dg_lds[part * LH + i]);
-            a0 = fmaf(wt[i], dv.x, a0); a1 = fmaf(wt[i + 1], dv.y, a1); a2 = fmaf(wt[i + 2], dv.z, a2); a3 = fmaf(wt[i + 3], dv.w, a3);
+            for (int ii = 0; ii < LH; ii += 4) {
+                float4 dv = *reinterpret_cast<const float4*>(&dgw[part * LH + ii]);      // written by this wave just above
+                a0 = fmaf(wt[ii], dv.x, a0); a1 = fmaf(wt[ii + 1], dv.y, a1); a2 = fmaf(wt[ii + 2], dv.z, a2); a3 = fmaf(wt[ii + 3], dv.w, a3);
+            }
+            float (*pl)[LH] = part_lds[i & 1];
+            pl[part][k] = (a0 + a1) + (a2 + a3);
+            __syncthreads();
+            dh = (pl[0][k] + pl[1][k]) + (pl[2][k] + pl[3][k]);
         }
-        part_lds[part][k] = (a0 + a1) + (a2 + a3);
-        __syncthreads();
-        if (j < LH) dh = (part_lds[0][j] + part_lds[1][j]) + (part_lds[2][j] + part_lds[3][j]);
     }
 }
 

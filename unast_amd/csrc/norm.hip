@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dz,
-                                                            float* __restrict__ dz_drop, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int rows, int C, int rows_per_block,
+                                                            float* __restrict__ dz_drop, float* __restrict__ part,
+                                                            int rows, int C, int rows_per_block,
                                                             uint32_t drop_thresh, float drop_scale, uint32_t seed, uint32_t stream) {
     __shared__ float red[2][4][LN_MAXV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
-    if (!dgamma) return;
-    // block reduction of the column partials (4 waves) then one atomic per column per block
+    if (!part) return;
+    // block reduction of the column partials (4 waves); one row of [2][C] partials per workgroup, summed by ln_bwd_finalize
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         int c = (lane + 64 * i) * 4;
@@ -135,8 +135,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int c = threadIdx.x; c < C; c += 256) {
         float sg = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
         float sb = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
-        atomicAdd(dgamma + c, sg);
-        atomicAdd(dbeta + c, sb);
+        part[((size_t)blockIdx.x * 2 + 0) * C + c] = sg;
+        part[((size_t)blockIdx.x * 2 + 1) * C + c] = sb;
+    }
+}
+
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    // 64 columns x 16 partial-row lanes per workgroup; columns index the concatenated [dgamma | dbeta] vector of 2C entries
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float a = 0.f;
+    if (c < 2 * C) {
+        const int which = c / C, col = c - which * C;
+        for (int b = ty; b < nblk; b += 16) a += part[((size_t)b * 2 + which) * C + col];
+    }
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && c < 2 * C) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][tx];
+        const int which = c / C, col = c - which * C;
+        (which ? dbeta : dgamma)[col] += s;
     }
 }
 
@@ -326,18 +347,31 @@ extern "C" int unast_layernorm_fwd(const float* z, const float* gamma, const flo
     return unast_check_launch("unast_layernorm_fwd");
 }
 
+static void ln_bwd_geometry(int rows, int* blocks, int* rpb) {
+    int b = grid_for(rows, 32, 1024);
+    *rpb = (rows + b - 1) / b;
+    *blocks = (rows + *rpb - 1) / *rpb;
+}
+
+extern "C" int64_t unast_layernorm_bwd_ws_floats(int rows, int C) {
+    int blocks, rpb;
+    ln_bwd_geometry(rows, &blocks, &rpb);
+    return (int64_t)blocks * 2 * C;
+}
+
 extern "C" int unast_layernorm_bwd(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd,
-                                   float* dz, float* dz_drop, float* dgamma, float* dbeta, int rows, int C,
+                                   float* dz, float* dz_drop, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, int rows, int C,
                                    float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream) {
     UNAST_REQUIRE(dy && z && gamma && mean && rstd && dz, "unast_layernorm_bwd: null pointer");
     UNAST_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "unast_layernorm_bwd: dgamma/dbeta must both be given or both null");
     UNAST_REQUIRE(rows > 0 && (C & 3) == 0 && C <= 1024, "unast_layernorm_bwd: need C%%4==0, C<=1024 (C=%d)", C);
-    int blocks = grid_for(rows, 32, 1024);
-    int rpb = (rows + blocks - 1) / blocks;
-    blocks = (rows + rpb - 1) / rpb;
+    int blocks, rpb;
+    ln_bwd_geometry(rows, &blocks, &rpb);
+    UNAST_REQUIRE(!dgamma || (ws && ws_floats >= (int64_t)blocks * 2 * C), "unast_layernorm_bwd: workspace too small (need %lld floats)", (long long)blocks * 2 * C);
     uint32_t th = dz_drop ? drop_threshold(drop_p) : 0u;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, z, gamma, mean, rstd, dz,
-                       (th ? dz_drop : (float*)nullptr), dgamma, dbeta, rows, C, rpb, th, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, stream_id);
+                       (th ? dz_drop : (float*)nullptr), (dgamma ? ws : (float*)nullptr), rows, C, rpb, th, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, stream_id);
+    if (dgamma) hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, ws, blocks, C, dgamma, dbeta);
     return unast_check_launch("unast_layernorm_bwd");
 }
 

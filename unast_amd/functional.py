@@ -99,8 +99,7 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
             da = dzd if p > 0 else dz
             gWo = st.g(pre_attn + "out_proj.weight")
             if gWo is not None:
-                ops.linear_wgrad(da, O, gWo)
-                ops.colsum(da, st.g(pre_attn + "out_proj.bias"))
+                ops.linear_wgrad(da, O, gWo, db=st.g(pre_attn + "out_proj.bias"))
             dO = _empty(Nq, E, like=z)
             ops.linear_dgrad(da, Wo, dO)
             delta = _empty(B, H, Tq, like=z)
@@ -110,8 +109,7 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
                 ops.attn_bwd(Q, K, V, O, dO, LSE, delta, dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:], lens_k, B, H, Tq, Tk, causal,
                              drop_p=p, seed=seed, stream_id=s_attn)
                 if gW is not None:
-                    ops.linear_wgrad(dqkv, x.v, gW)
-                    ops.colsum(dqkv, gb)
+                    ops.linear_wgrad(dqkv, x.v, gW, db=gb)
                 dx = _empty(Nq, E, like=z)
                 ops.linear_dgrad(dqkv, W, dx, R=dz)
             else:
@@ -120,10 +118,8 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
                 ops.attn_bwd(Q, K, V, O, dO, LSE, delta, dq, dkv[:, :E], dkv[:, E:], lens_k, B, H, Tq, Tk, causal,
                              drop_p=p, seed=seed, stream_id=s_attn)
                 if gW is not None:
-                    ops.linear_wgrad(dq, x.v, gW[:E])
-                    ops.linear_wgrad(dkv, mem.v, gW[E:])
-                    ops.colsum(dq, gb[:E])
-                    ops.colsum(dkv, gb[E:])
+                    ops.linear_wgrad(dq, x.v, gW[:E], db=gb[:E])
+                    ops.linear_wgrad(dkv, mem.v, gW[E:], db=gb[E:])
                 dx = _empty(Nq, E, like=z)
                 ops.linear_dgrad(dq, W[:E], dx, R=dz)
                 dmem = _empty(Nk, E, like=z)
@@ -161,14 +157,12 @@ def ffn_sublayer(cx, tape, x, pre, pre_norm, drop):
             da = dzd if p > 0 else dz
             g2 = st.g(pre + "linear2.weight")
             if g2 is not None:
-                ops.linear_wgrad(da, h, g2)
-                ops.colsum(da, st.g(pre + "linear2.bias"))
+                ops.linear_wgrad(da, h, g2, db=st.g(pre + "linear2.bias"))
             du = _empty(N, F, like=z)
             ops.linear_dgrad(da, W2, du, G=h, gate_scale=(1.0 / (1.0 - p) if p > 0 else 1.0))      # relu' and dropout mask from h > 0
             g1 = st.g(pre + "linear1.weight")
             if g1 is not None:
-                ops.linear_wgrad(du, x.v, g1)
-                ops.colsum(du, st.g(pre + "linear1.bias"))
+                ops.linear_wgrad(du, x.v, g1, db=st.g(pre + "linear1.bias"))
             dx = _empty(N, E, like=z)
             ops.linear_dgrad(du, W1, dx, R=dz)
             acc(x, dx)
@@ -256,8 +250,7 @@ def conv_bn_act(cx, tape, x, B, T, conv_pre, bn_pre, pad_left, act, drop, bn_buf
             gW = st.g(conv_pre + "conv.weight")
             dc3 = dc.view(B, T, Cout)
             if gW is not None:
-                ops.conv_wgrad(dc3, x3, gW, pad_left)
-                ops.colsum(dc, st.g(conv_pre + "conv.bias"))
+                ops.conv_wgrad(dc3, x3, gW, pad_left, db=st.g(conv_pre + "conv.bias"))
             dx = _empty(B, T, Cin, like=y)
             ops.conv_dgrad(dc3, Wp, dx, pad_left)
             acc(x, dx.view(N, Cin))
@@ -330,8 +323,7 @@ def text_decode(cx, tape, m, ids, lens_q, mem, lens_k, Tk):
             dl = out.g
             gW = st.g("text_m.postnet.fc1.weight")
             if gW is not None:
-                ops.linear_wgrad(dl[:, :V], xd, gW)
-                ops.colsum(dl[:, :V], st.g("text_m.postnet.fc1.bias"))
+                ops.linear_wgrad(dl[:, :V], xd, gW, db=st.g("text_m.postnet.fc1.bias"))
             dxd = _empty(N, E, like=xd)
             ops.linear_dgrad(dl[:, :V], W, dxd)
             if p > 0:
@@ -367,12 +359,10 @@ def speech_prenet(cx, tape, m, mel2d, T):
             g2 = st.g("speech_m.prenet.layer.fc2.linear_layer.weight")
             if d2 is None or g2 is None:
                 return
-            ops.linear_wgrad(d2, h1, g2)
-            ops.colsum(d2, st.g("speech_m.prenet.layer.fc2.linear_layer.bias"))
+            ops.linear_wgrad(d2, h1, g2, db=st.g("speech_m.prenet.layer.fc2.linear_layer.bias"))
             du = _empty(N, W1.shape[0], like=h1)
             ops.linear_dgrad(d2, W2, du, G=h1, gate_scale=(1.0 / (1.0 - p) if p > 0 else 1.0))
-            ops.linear_wgrad(du, mel2d, st.g("speech_m.prenet.layer.fc1.linear_layer.weight"))
-            ops.colsum(du, st.g("speech_m.prenet.layer.fc1.linear_layer.bias"))
+            ops.linear_wgrad(du, mel2d, st.g("speech_m.prenet.layer.fc1.linear_layer.weight"), db=st.g("speech_m.prenet.layer.fc1.linear_layer.bias"))
         tape.record(bwd)                                # recorded before posenc's closure => runs after it
     y = posenc(cx, tape, h2v, m.pe, T, gate=h2)
     return y
@@ -423,8 +413,7 @@ def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk):
                 ops.add_strided(dh, postv.g, M)
             gW = st.gspan("speech_m.postnet.linear_project.weight", "speech_m.postnet.stop_linear.weight", (M + 1, E))
             if gW is not None:
-                ops.linear_wgrad(dh[:, :M + 1], x.v, gW)
-                ops.colsum(dh[:, :M + 1], st.gspan("speech_m.postnet.linear_project.bias", "speech_m.postnet.stop_linear.bias", (M + 1,)))
+                ops.linear_wgrad(dh[:, :M + 1], x.v, gW, db=st.gspan("speech_m.postnet.linear_project.bias", "speech_m.postnet.stop_linear.bias", (M + 1,)))
             dx = _empty(N, E, like=x.v)
             ops.linear_dgrad(dh[:, :M + 1], Wh, dx)
             acc(x, dx)
@@ -447,8 +436,7 @@ def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk):
             gW = st.g("speech_m.postnet.conv2.conv.weight")
             dp3 = dp.view(B, T, M)
             if gW is not None:
-                ops.conv_wgrad(dp3, y.v.view(B, T, C), gW, 4)
-                ops.colsum(dp, st.g("speech_m.postnet.conv2.conv.bias"))
+                ops.conv_wgrad(dp3, y.v.view(B, T, C), gW, 4, db=st.g("speech_m.postnet.conv2.conv.bias"))
             dy = _empty(B, T, C, like=dp)
             ops.conv_dgrad(dp3, Wp2, dy, 4)
             acc(y, dy.view(N, C))
@@ -523,8 +511,7 @@ def lstm_discriminator(cx, tape, m, x, lens, Bd, T, need_input_grad=True):
             dl = out.g                                             # [Bd,4], column 0 valid
             g2 = st.g("discriminator.fc2.weight")
             if g2 is not None:
-                ops.linear_wgrad(dl[:, :1], a, g2)
-                ops.colsum(dl[:, :1], st.g("discriminator.fc2.bias"))
+                ops.linear_wgrad(dl[:, :1], a, g2, db=st.g("discriminator.fc2.bias"))
             da = _empty(Bd, Hh, device=dev)
             ops.linear_dgrad(dl[:, :1], W2, da)
             dr = _empty(Bd, Hh, device=dev)
@@ -532,8 +519,7 @@ def lstm_discriminator(cx, tape, m, x, lens, Bd, T, need_input_grad=True):
             if ndir == 2:
                 gr = st.g("discriminator.rnn.reduce_h_W.weight")
                 if gr is not None:
-                    ops.linear_wgrad(dr, hfin, gr)
-                    ops.colsum(dr, st.g("discriminator.rnn.reduce_h_W.bias"))
+                    ops.linear_wgrad(dr, hfin, gr, db=st.g("discriminator.rnn.reduce_h_W.bias"))
                 dhf = _empty(Bd, ndir * Hh, device=dev)
                 ops.linear_dgrad(dr, Wr, dhf)
             else:
@@ -547,12 +533,11 @@ def lstm_discriminator(cx, tape, m, x, lens, Bd, T, need_input_grad=True):
                 names, last = rec["names"], rec["last"]
                 gWih = st.gspan(names[0], last[0], (ndir * G4, rec["din"]))
                 if gWih is not None:
-                    ops.linear_wgrad(dg2, rec["inp"].v, gWih)
+                    ops.linear_wgrad(dg2, rec["inp"].v, gWih, db=st.gspan(names[2], last[2], (ndir * G4,)))
                     gWhh = st.gspan(names[1], last[1], (ndir * G4, Hh))
                     hp = rec["hprev"].view(Bd * T, ndir * Hh)
                     for d in range(ndir):
                         ops.linear_wgrad(dg2[:, d * G4:(d + 1) * G4], hp[:, d * Hh:(d + 1) * Hh], gWhh[d * G4:(d + 1) * G4])
-                    ops.colsum(dg2, st.gspan(names[2], last[2], (ndir * G4,)))
                     ops.colsum(dg2, st.gspan(names[3], last[3], (ndir * G4,)))
                 need_dx = rec["l"] > 0 or need_input_grad
                 if not need_dx:

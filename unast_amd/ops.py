@@ -27,7 +27,7 @@ def _f32(t, name):
 
 
 def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bias=None, R=None, ldr=0, G=None,
-         ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False):
+         ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False, rowsum_a=None):
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (R, "R"), (G, "G")):
         _f32(t, n)
     ws, ws_n = None, 0
@@ -36,7 +36,7 @@ def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bia
         ws = torch.empty(ws_n, dtype=torch.float32, device=C.device)          # split-K partial slabs (caching allocator)
     check(lib().unast_gemm(a_mode, b_mode, nsplit or config.NSPLIT, _p(A), lda, _p(B), ldb, _p(C), ldc, M, N, K,
                            conv[0], conv[1], conv[2], conv[3], _p(bias), _p(R), ldr, _p(G), ldg, gate_scale,
-                           alpha, beta, act, drop_p, seed & 0xFFFFFFFF, stream_id, splitk, _p(ws), ws_n, _stream()), "unast_gemm")
+                           alpha, beta, act, drop_p, seed & 0xFFFFFFFF, stream_id, splitk, _p(ws), ws_n, _p(rowsum_a), _stream()), "unast_gemm")
 
 
 SPLITK_TARGET_BLOCKS = 320
@@ -71,12 +71,12 @@ def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0):
     return dx
 
 
-def linear_wgrad(dy2d, x2d, dW):
-    """dW[N,K] += dy2d[M,N]^T @ x2d[M,K]  (always accumulates; split-K with fp32 atomics)."""
+def linear_wgrad(dy2d, x2d, dW, db=None):
+    """dW[N,K] += dy2d[M,N]^T @ x2d[M,K]; optionally db[N] += sum_rows dy2d (fused).  Always accumulates."""
     M, N = dy2d.shape
     K = x2d.shape[1]
     sk = _splitk_for(N, K, M)
-    gemm(OP_RC, OP_RC, dy2d, dy2d.stride(0), x2d, x2d.stride(0), dW, dW.stride(0), N, K, M, beta=1, splitk=sk)
+    gemm(OP_RC, OP_RC, dy2d, dy2d.stride(0), x2d, x2d.stride(0), dW, dW.stride(0), N, K, M, beta=1, splitk=sk, rowsum_a=db)
     return dW
 
 
@@ -97,13 +97,13 @@ def conv_dgrad(dy3d, Wp, dx, pad_left, beta=0):
     return dx
 
 
-def conv_wgrad(dy3d, x3d, dWp, pad_left):
-    """dWp[Cout,5,Cin] += sum_t dy[t,o] x[t+j-pad_left,c]."""
+def conv_wgrad(dy3d, x3d, dWp, pad_left, db=None):
+    """dWp[Cout,5,Cin] += sum_t dy[t,o] x[t+j-pad_left,c]; optionally db[Cout] += sum_t dy (fused)."""
     B, T, Cout = dy3d.shape
     Cin = x3d.shape[2]
     sk = _splitk_for(Cout, 5 * Cin, B * T)
     gemm(OP_RC, OP_RC_CONV_WGRAD, dy3d, dy3d.stride(1), x3d, x3d.stride(1), dWp, 5 * Cin, Cout, 5 * Cin, B * T,
-         conv=(T, 0, Cin, pad_left), beta=1, splitk=sk)
+         conv=(T, 0, Cin, pad_left), beta=1, splitk=sk, rowsum_a=db)
     return dWp
 
 
@@ -130,8 +130,12 @@ def layernorm_fwd(z, gamma, beta, y, mean, rstd, eps=1e-5):
 
 def layernorm_bwd(dy, z, gamma, mean, rstd, dz, dz_drop=None, dgamma=None, dbeta=None, drop_p=0.0, seed=0, stream_id=0):
     rows, C = z.shape
-    check(lib().unast_layernorm_bwd(_p(dy), _p(z), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dz_drop), _p(dgamma), _p(dbeta), rows, C,
-                                    drop_p, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_layernorm_bwd")
+    ws, ws_n = None, 0
+    if dgamma is not None:
+        ws_n = lib().unast_layernorm_bwd_ws_floats(rows, C)
+        ws = torch.empty(ws_n, dtype=torch.float32, device=z.device)
+    check(lib().unast_layernorm_bwd(_p(dy), _p(z), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dz_drop), _p(dgamma), _p(dbeta), _p(ws), ws_n,
+                                    rows, C, drop_p, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_layernorm_bwd")
 
 
 def colsum(x2d, out):
