@@ -99,7 +99,7 @@ __device__ __forceinline__ void tile_store(const float4 (&r)[NROWS / 16], unsign
 // grid (ceil(Tq/128), H, B), 256 threads; wave w owns queries [128*bx + 32w, +32).
 // ------------------------------------------------------------------------------------------------------------
 template <int NSPLIT, int MODE>
-__global__ __launch_bounds__(256) void attn_q_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
     constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
     constexpr int IMG = 64 * ALD * 2;                         // one 64-row image
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PARTS * IMG];
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnParams p) {
 // accumulators while the workgroup sweeps 32-query tiles of Q and dO through LDS.
 // ------------------------------------------------------------------------------------------------------------
 template <int NSPLIT>
-__global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
     constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
     constexpr int IMG = 32 * ALD * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PARTS * IMG];
