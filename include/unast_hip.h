@@ -31,6 +31,8 @@ const char* unast_arch(void);
  * src/module.py:306-310 (LSTM input projections, reduce_h_W), src/network.py:182 (fc2).
  * a_mode/b_mode: 0 K-contiguous, 1 K-contiguous conv gather (A only), 2 row-contiguous,
  *                3 conv-dgrad weights (B only), 4 conv-wgrad gather (B only).
+ * K must be a multiple of 4 for K-contiguous operands (zero-pad); kb_valid (<= K, 0 = K) is the number of rows of a
+ * row-contiguous B that really exist, so a zero-padded A can be multiplied by an un-padded weight.
  * Epilogue: x = alpha*acc (+bias[n]) -> relu if act==1 -> dropout(drop_p) -> gate (G>0 ? x*gate_scale : 0)
  *           -> + R[m,n] -> (+C if beta).  split-K (splitk>1, plain alpha/beta epilogue only): partial sums go to
  *           splitk_ws ([splitk][M][ceil4(N)] floats, caller-owned) and a second launch reduces them into C; with
@@ -39,7 +41,7 @@ const char* unast_arch(void);
  *           the weight-gradient pass that already streams dY. */
 int unast_gemm(int a_mode, int b_mode, int nsplit,
                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-               int M, int N, int K,
+               int M, int N, int K, int kb_valid,
                int conv_T, int conv_ca, int conv_cb, int conv_shift,
                const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale,
                float alpha, int beta, int act,

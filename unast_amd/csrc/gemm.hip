@@ -34,6 +34,7 @@ struct GemmParams {
     uint32_t drop_thresh; float drop_scale; uint32_t seed, stream;
     int kchunk; int atomic; int tiles_m, tiles_n;
     float* slab; int ld_slab; size_t slab_stride;     // split-K partial slabs [z][M][ld_slab]
+    int kb_valid;                                     // rows of a row-contiguous B that exist (K may be zero-padded above it)
     float* rowsum_a;                                  // optional: rowsum_a[m] += sum_k A[m][k] (bias gradient fused into wgrad)
 };
 
@@ -42,58 +43,54 @@ __device__ __forceinline__ int kc_off(int row, int k) {      // byte offset of e
     return row * 64 + ((((k >> 3) ^ swz_h(row))) << 4) + ((k & 7) << 1);
 }
 
+// Tile loads are UNCONDITIONAL (clamped address, then select-to-zero): branches around loads make hipcc wait for each
+// load separately and serialise the staging.  Contract checked on the host: K % 4 == 0 for K-contiguous operands,
+// ld >= ceil4(rows) for row-contiguous operands (junk in the pad only reaches rows/columns that are never stored).
 template <int MODE>
 __device__ __forceinline__ float4 load_kc(const GemmParams& p, const float* __restrict__ src, int ld, int nrows,
                                           int row, int k, int kend, int conv_rb, int conv_rt) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows && k < kend) {
-        if (MODE == OP_KC) {
-            const float* ptr = src + (size_t)row * ld + k;
-            if (k + 3 < kend) {
-                v = *reinterpret_cast<const float4*>(ptr);
-            } else {
-                v.x = ptr[0];
-                if (k + 1 < kend) v.y = ptr[1];
-                if (k + 2 < kend) v.z = ptr[2];
-            }
-        } else {   // OP_KC_CONV: A[(b,t)][(j,c)] = X[b, t + j - shift, c]
-            int j = k / p.ca;
-            int c = k - j * p.ca;
-            int ts = conv_rt + j - p.shift;
-            if (ts >= 0 && ts < p.T) v = *reinterpret_cast<const float4*>(src + (size_t)(conv_rb + ts) * ld + c);
-        }
+    bool ok = row < nrows && k < kend;
+    const int rr = min(row, nrows - 1);
+    const int kk = min(k, p.K - 4);
+    const float* ptr;
+    if (MODE == OP_KC) {
+        ptr = src + (size_t)rr * ld + kk;
+    } else {       // OP_KC_CONV: A[(b,t)][(j,c)] = X[b, t + j - shift, c]
+        const int j = kk / p.ca;
+        const int c = kk - j * p.ca;
+        const int ts = conv_rt + j - p.shift;
+        ok = ok && ts >= 0 && ts < p.T;
+        const int tc = min(max(ts, 0), p.T - 1);
+        ptr = src + (size_t)(conv_rb + tc) * ld + c;
     }
+    float4 v = *reinterpret_cast<const float4*>(ptr);
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
     return v;
 }
 
 template <int MODE>
 __device__ __forceinline__ float4 load_rc(const GemmParams& p, const float* __restrict__ src, int ld, int nrows,
-                                          int row, int k, int kend, int conv_j, int conv_c) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows && k < kend) {
-        if (MODE == OP_RC_CONV_WGRAD) {     // B[(b,t)][(j,c)] = X[b, t + j - shift, c]
-            int b = k / p.T;
-            int tt = k - b * p.T;
-            int ts = tt + conv_j - p.shift;
-            if (ts >= 0 && ts < p.T) v = *reinterpret_cast<const float4*>(src + (size_t)(b * p.T + ts) * ld + conv_c);
-        } else {
-            const float* ptr;
-            if (MODE == OP_RC) {
-                ptr = src + (size_t)k * ld + row;
-            } else {                        // OP_RC_CONV_DGRAD: B[c][(j',o)] = Wp[o][KS-1-j'][c], Wp = [O][KS][C]
-                int jj = k / p.cb;
-                int o = k - jj * p.cb;
-                ptr = src + ((size_t)o * p.KS + (p.KS - 1 - jj)) * nrows + row;
-            }
-            if (row + 3 < nrows) {
-                v = *reinterpret_cast<const float4*>(ptr);
-            } else {
-                v.x = ptr[0];
-                if (row + 1 < nrows) v.y = ptr[1];
-                if (row + 2 < nrows) v.z = ptr[2];
-            }
-        }
+                                          int row, int k, int kend, int kvalid, int conv_j, int conv_c) {
+    bool ok = row < nrows && k < kend && k < kvalid;
+    const int rr = (row < nrows) ? row : 0;
+    const int kk = min(k, kvalid - 1);
+    const float* ptr;
+    if (MODE == OP_RC_CONV_WGRAD) {     // B[(b,t)][(j,c)] = X[b, t + j - shift, c]
+        const int b = kk / p.T;
+        const int tt = kk - b * p.T;
+        const int ts = tt + conv_j - p.shift;
+        ok = ok && ts >= 0 && ts < p.T;
+        const int tc = min(max(ts, 0), p.T - 1);
+        ptr = src + (size_t)(b * p.T + tc) * ld + ((row < nrows) ? conv_c : 0);
+    } else if (MODE == OP_RC) {
+        ptr = src + (size_t)kk * ld + rr;
+    } else {                            // OP_RC_CONV_DGRAD: B[c][(j',o)] = Wp[o][KS-1-j'][c], Wp = [O][KS][C]
+        const int jj = kk / p.cb;
+        const int o = kk - jj * p.cb;
+        ptr = src + ((size_t)o * p.KS + (p.KS - 1 - jj)) * nrows + rr;
     }
+    float4 v = *reinterpret_cast<const float4*>(ptr);
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
     return v;
 }
 
@@ -135,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     if (AM == OP_KC_CONV) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int row = m0 + (t >> 3) + 32 * i;
+            int row = min(m0 + (t >> 3) + 32 * i, p.M - 1);     // clamped: loads are unconditional (rows >= M are zeroed after the load)
             int b = row / p.T;
             a_rb[i] = b * p.T;
             a_rt[i] = row - b * p.T;
@@ -143,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
     int b_cj = 0, b_cc = 0;                 // conv-wgrad B: tap and channel of this thread's 4 columns
     if (BMODE == OP_RC_CONV_WGRAD) {
-        int row = n0 + (t & 31) * 4;
+        int row = min(n0 + (t & 31) * 4, p.N - 4);          // clamped for the same reason (N = 5*cb is a multiple of 4)
         b_cj = row / p.cb;
         b_cc = row - b_cj * p.cb;
     }
@@ -153,9 +150,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (A_KC) ra[i] = load_kc<AM>(p, p.A, p.lda, p.M, m0 + (t >> 3) + 32 * i, k0 + (t & 7) * 4, kend, a_rb[i], a_rt[i]);
-            else      ra[i] = load_rc<AM>(p, p.A, p.lda, p.M, m0 + (t & 31) * 4, k0 + (t >> 5) + 8 * i, kend, 0, 0);
+            else      ra[i] = load_rc<AM>(p, p.A, p.lda, p.M, m0 + (t & 31) * 4, k0 + (t >> 5) + 8 * i, kend, p.K, 0, 0);
             if (B_KC) rb[i] = load_kc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t >> 3) + 32 * i, k0 + (t & 7) * 4, kend, 0, 0);
-            else      rb[i] = load_rc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t & 31) * 4, k0 + (t >> 5) + 8 * i, kend, b_cj, b_cc);
+            else      rb[i] = load_rc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t & 31) * 4, k0 + (t >> 5) + 8 * i, kend, p.kb_valid, b_cj, b_cc);
         }
     };
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -361,7 +358,7 @@ static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
                           const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                          int M, int N, int K,
+                          int M, int N, int K, int kb_valid,
                           int conv_T, int conv_ca, int conv_cb, int conv_shift,
                           const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale,
                           float alpha, int beta, int act,
@@ -373,6 +370,11 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     UNAST_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C), "unast_gemm: operands must be 16-byte aligned");
     UNAST_REQUIRE((lda & 3) == 0 && (ldb & 3) == 0, "unast_gemm: lda/ldb must be multiples of 4 (got %d, %d)", lda, ldb);
     UNAST_REQUIRE(splitk >= 1, "unast_gemm: splitk >= 1");
+    const bool a_kc = (a_mode == OP_KC || a_mode == OP_KC_CONV), b_kc = (b_mode == OP_KC);
+    UNAST_REQUIRE(!(a_kc || b_kc) || ((K & 3) == 0 && K >= 4), "unast_gemm: K-contiguous operands need K %% 4 == 0 (zero-pad the operand; K=%d)", K);
+    UNAST_REQUIRE(a_kc || lda >= ((M + 3) & ~3), "unast_gemm: row-contiguous A needs lda >= ceil4(M)");
+    UNAST_REQUIRE(b_kc || b_mode != OP_RC || ldb >= ((N + 3) & ~3), "unast_gemm: row-contiguous B needs ldb >= ceil4(N)");
+    if (kb_valid <= 0 || kb_valid > K) kb_valid = K;
     UNAST_REQUIRE(!(splitk > 1 && (act || drop_p > 0.f || G || bias || R)),
                   "unast_gemm: split-K supports only the plain alpha/beta epilogue");
     UNAST_REQUIRE(!(splitk > 1 && !splitk_ws && beta == 0), "unast_gemm: atomic split-K (no workspace) accumulates into C: needs beta=1");
@@ -392,6 +394,7 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     splitk = (ksteps + steps_per - 1) / steps_per;
     p.slab = nullptr; p.ld_slab = 0; p.slab_stride = 0;
     p.rowsum_a = rowsum_a;
+    p.kb_valid = kb_valid;
     UNAST_REQUIRE(!rowsum_a || a_mode == OP_RC, "unast_gemm: rowsum_a needs a row-contiguous A operand (weight-gradient form)");
     p.atomic = 0;
     if (splitk > 1) {

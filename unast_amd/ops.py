@@ -27,14 +27,14 @@ def _f32(t, name):
 
 
 def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bias=None, R=None, ldr=0, G=None,
-         ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False, rowsum_a=None):
+         ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False, rowsum_a=None, kb_valid=0):
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (R, "R"), (G, "G")):
         _f32(t, n)
     ws, ws_n = None, 0
     if splitk > 1 and not atomic:
         ws_n = splitk * M * ((N + 3) // 4 * 4)
         ws = torch.empty(ws_n, dtype=torch.float32, device=C.device)          # split-K partial slabs (caching allocator)
-    check(lib().unast_gemm(a_mode, b_mode, nsplit or config.NSPLIT, _p(A), lda, _p(B), ldb, _p(C), ldc, M, N, K,
+    check(lib().unast_gemm(a_mode, b_mode, nsplit or config.NSPLIT, _p(A), lda, _p(B), ldb, _p(C), ldc, M, N, K, kb_valid,
                            conv[0], conv[1], conv[2], conv[3], _p(bias), _p(R), ldr, _p(G), ldg, gate_scale,
                            alpha, beta, act, drop_p, seed & 0xFFFFFFFF, stream_id, splitk, _p(ws), ws_n, _p(rowsum_a), _stream()), "unast_gemm")
 
@@ -65,9 +65,12 @@ def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0):
     """dx[M,K] = (dy2d[M,N] @ W[N,K]) gated by G>0, + R."""
     M, N = dy2d.shape
     K = W.shape[1]
-    gemm(OP_KC, OP_RC, dy2d, dy2d.stride(0), W, W.stride(0), dx, dx.stride(0), M, K, N, R=R,
+    Np = (N + 3) // 4 * 4          # dy2d is a view of a zero-padded buffer when N % 4 != 0 (logits 46->48, head 81->84, fc2 1->4)
+    if Np != N and dy2d.stride(0) < Np:
+        raise ValueError("linear_dgrad: dy must live in a zero-padded buffer with row stride >= %d" % Np)
+    gemm(OP_KC, OP_RC, dy2d, dy2d.stride(0), W, W.stride(0), dx, dx.stride(0), M, K, Np, R=R,
          ldr=(R.stride(0) if R is not None else 0), G=G, ldg=(G.stride(0) if G is not None else 0),
-         gate_scale=gate_scale, beta=beta)
+         gate_scale=gate_scale, beta=beta, kb_valid=N)
     return dx
 
 
