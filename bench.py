@@ -185,6 +185,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(a.steps):
             one_step(a.warmup + i)
+        t_host = time.perf_counter() - t0          # host-side enqueue time (kernels run asynchronously)
         sync()
         dt = time.perf_counter() - t0
     if world > 1:
@@ -228,6 +229,7 @@ def main():
                                   "num_layers=%d, d=256, 4 heads, FFN 1024, 2x bi-LSTM(64) discriminator, dropout/noise/SpecAugment active" % (a.workload, B, Tt, Tm, L),
                       "global_batch": B * world, "parallelism": "dp%d" % world,
                       "precision": "split-bf16 (hi/lo) MFMA operands, fp32 accumulate and fp32 activations" if config.NSPLIT == 3 else "bf16 MFMA operands, fp32 accumulate"},
+           "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
            "losses_finite": finite, "last_losses": {k: round(v, 5) for k, v in last.items()},
            "roofline": roofline}
     if world == 1 and not a.no_cpu_baseline:

@@ -214,25 +214,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             }
     };
 
-    // Two register sets keep tiles kt+1 and kt+2 in flight while tile kt is multiplied; two LDS stages need a single
-    // barrier per k-step (a stage is rewritten only after every wave has passed the barrier that follows its last read).
+    // Two-stage software pipeline, one barrier per k-step.  In iteration kt a wave (1) issues the global loads of tile
+    // kt+2 into the register set that was drained one iteration ago, (2) multiplies tile kt from LDS stage kt%2 and, in
+    // the shadow of those MFMAs, converts tile kt+1 (whose loads were issued an iteration ago) and writes it to the
+    // other LDS stage.  Loads are issued unconditionally (clamped addresses) so the compiler's vmcnt counts are static.
     float4 ra0[4], rb0[4], ra1[4], rb1[4];
     unsigned char* const s0A = smem;
     unsigned char* const s0B = smem + A_BYTES * PARTS;
     unsigned char* const s1A = smem + STAGE;
     unsigned char* const s1B = smem + STAGE + A_BYTES * PARTS;
-    if (nk > 0) load_tiles(0, ra0, rb0);
-    if (nk > 1) load_tiles(1, ra1, rb1);
+    load_tiles(0, ra0, rb0);
+    load_tiles(1, ra1, rb1);
+    store_tiles(ra0, rb0, s0A, s0B);
+    __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
-        store_tiles(ra0, rb0, s0A, s0B);
-        __syncthreads();
-        if (kt + 2 < nk) load_tiles(kt + 2, ra0, rb0);
+        load_tiles(kt + 2, ra0, rb0);
         compute(s0A, s0B);
+        store_tiles(ra1, rb1, s1A, s1B);
+        __syncthreads();
         if (kt + 1 < nk) {
-            store_tiles(ra1, rb1, s1A, s1B);
-            __syncthreads();
-            if (kt + 3 < nk) load_tiles(kt + 3, ra1, rb1);
+            load_tiles(kt + 3, ra1, rb1);
             compute(s1A, s1B);
+            store_tiles(ra0, rb0, s0A, s0B);
+            __syncthreads();
         }
     }
 
