@@ -38,7 +38,9 @@ const char* unast_arch(void);
  *           splitk_ws ([splitk][M][ceil4(N)] floats, caller-owned) and a second launch reduces them into C; with
  *           splitk_ws == NULL the partials are added to C with fp32 atomics (needs beta=1).
  * rowsum_a (a_mode 2 only, may be NULL): rowsum_a[m] += sum_k A[m][k] — the bias gradient sum_tokens dY fused into
- *           the weight-gradient pass that already streams dY. */
+ *           the weight-gradient pass that already streams dY.
+ * tile_wn: block tile width 64*tile_wn columns (2 or 4); 0 lets the library choose (128x256 when N >= 192 and the
+ *           grid still fills the chip). */
 int unast_gemm(int a_mode, int b_mode, int nsplit,
                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                int M, int N, int K, int kb_valid,
@@ -46,7 +48,7 @@ int unast_gemm(int a_mode, int b_mode, int nsplit,
                const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale,
                float alpha, int beta, int act,
                float drop_p, unsigned int seed, unsigned int stream_id,
-               int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, hipStream_t stream);
+               int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, int tile_wn, hipStream_t stream);
 
 /* Fused multi-head attention core (head_dim 64), flash-style.  Replaces the softmax(QK^T/sqrt(d)+mask) -> dropout -> V
  * core of torch.nn.MultiheadAttention inside torch.nn.TransformerEncoderLayer/DecoderLayer

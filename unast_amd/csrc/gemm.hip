@@ -16,11 +16,12 @@
 #include "common.h"
 
 #define GBM 128
-#define GBN 128
 #define GBK 32
-#define RC_STRIDE (GBM + 16)                 // bf16 elements per k-row of a row-contiguous image (288 B)
-#define KC_BYTES (GBM * GBK * 2)             // 8192
-#define RC_BYTES (GBK * RC_STRIDE * 2)       // 9216
+// Block tile = 128 x (64*WN): WN = 2 (256 threads) or 4 (512 threads, 128x256 tile).  The wide tile halves the A-operand
+// bytes a CU has to pull through its vector-memory path per FLOP, which is what bounds these fp32-operand GEMMs.
+__host__ __device__ constexpr int rc_stride(int rows) { return rows + 16; }            // bf16 elements per k-row of a [k][row] image
+__host__ __device__ constexpr int kc_bytes(int rows) { return rows * GBK * 2; }
+__host__ __device__ constexpr int rc_bytes(int rows) { return GBK * rc_stride(rows) * 2; }
 
 enum { OP_KC = 0, OP_KC_CONV = 1, OP_RC = 2, OP_RC_CONV_DGRAD = 3, OP_RC_CONV_WGRAD = 4 };
 
@@ -94,13 +95,21 @@ __device__ __forceinline__ float4 load_rc(const GemmParams& p, const float* __re
     return v;
 }
 
-template <int AM, int BMODE, int NSPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+template <int AM, int BMODE, int NSPLIT, int WN>
+__global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_kernel(const GemmParams p) {
     constexpr bool A_KC = (AM == OP_KC || AM == OP_KC_CONV);
     constexpr bool B_KC = (BMODE == OP_KC);
     constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
-    constexpr int A_BYTES = A_KC ? KC_BYTES : RC_BYTES;
-    constexpr int B_BYTES = B_KC ? KC_BYTES : RC_BYTES;
+    constexpr int NT = 128 * WN;                       // threads
+    constexpr int GBN = 64 * WN;                       // block tile columns
+    constexpr int A_BYTES = A_KC ? kc_bytes(GBM) : rc_bytes(GBM);
+    constexpr int B_BYTES = B_KC ? kc_bytes(GBN) : rc_bytes(GBN);
+    constexpr int A_RCS = rc_stride(GBM), B_RCS = rc_stride(GBN);
+    // loader geometry: K-contiguous: 8 threads per 128-B row piece; row-contiguous: ROWS/4 threads per k-row
+    constexpr int A_PASS = (GBM * 8) / NT, B_PASS = (GBN * 8) / NT;          // float4 per thread per tile
+    constexpr int KC_RPP = NT / 8;                                           // rows per pass (K-contiguous)
+    constexpr int A_TPK = GBM / 4, B_TPK = GBN / 4;                          // threads per k-row (row-contiguous)
+    constexpr int A_KPP = NT / A_TPK, B_KPP = NT / B_TPK;                    // k-rows per pass
     constexpr int STAGE = (A_BYTES + B_BYTES) * PARTS;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];      // two stages: one barrier per k-step
 
@@ -124,15 +133,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, g = lane >> 4;
 
     // ---- per-thread loader coordinates -------------------------------------------------------
-    int a_rb[4] = {0, 0, 0, 0}, a_rt[4] = {0, 0, 0, 0};   // conv A: batch row base / time index of the 4 tile rows of this thread
+    int a_rb[A_PASS], a_rt[A_PASS];   // conv A: batch row base / time index of the tile rows of this thread
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) { a_rb[i] = 0; a_rt[i] = 0; }
     if (AM == OP_KC_CONV) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int row = min(m0 + (t >> 3) + 32 * i, p.M - 1);     // clamped: loads are unconditional (rows >= M are zeroed after the load)
+        for (int i = 0; i < A_PASS; ++i) {
+            int row = min(m0 + (t >> 3) + KC_RPP * i, p.M - 1);     // clamped: loads are unconditional (rows >= M are zeroed after the load)
             int b = row / p.T;
             a_rb[i] = b * p.T;
             a_rt[i] = row - b * p.T;
@@ -140,47 +151,54 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
     int b_cj = 0, b_cc = 0;                 // conv-wgrad B: tap and channel of this thread's 4 columns
     if (BMODE == OP_RC_CONV_WGRAD) {
-        int row = min(n0 + (t & 31) * 4, p.N - 4);          // clamped for the same reason (N = 5*cb is a multiple of 4)
+        int row = min(n0 + (t % B_TPK) * 4, p.N - 4);       // clamped for the same reason (N = 5*cb is a multiple of 4)
         b_cj = row / p.cb;
         b_cc = row - b_cj * p.cb;
     }
 
-    auto load_tiles = [&](int kt, float4 (&ra)[4], float4 (&rb)[4]) {
+    auto load_tiles = [&](int kt, float4 (&ra)[A_PASS], float4 (&rb)[B_PASS]) {
         const int k0 = kbeg + kt * GBK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (A_KC) ra[i] = load_kc<AM>(p, p.A, p.lda, p.M, m0 + (t >> 3) + 32 * i, k0 + (t & 7) * 4, kend, a_rb[i], a_rt[i]);
-            else      ra[i] = load_rc<AM>(p, p.A, p.lda, p.M, m0 + (t & 31) * 4, k0 + (t >> 5) + 8 * i, kend, p.K, 0, 0);
-            if (B_KC) rb[i] = load_kc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t >> 3) + 32 * i, k0 + (t & 7) * 4, kend, 0, 0);
-            else      rb[i] = load_rc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t & 31) * 4, k0 + (t >> 5) + 8 * i, kend, p.kb_valid, b_cj, b_cc);
+        for (int i = 0; i < A_PASS; ++i) {
+            if (A_KC) ra[i] = load_kc<AM>(p, p.A, p.lda, p.M, m0 + (t >> 3) + KC_RPP * i, k0 + (t & 7) * 4, kend, a_rb[i], a_rt[i]);
+            else      ra[i] = load_rc<AM>(p, p.A, p.lda, p.M, m0 + (t % A_TPK) * 4, k0 + t / A_TPK + A_KPP * i, kend, p.K, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+            if (B_KC) rb[i] = load_kc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t >> 3) + KC_RPP * i, k0 + (t & 7) * 4, kend, 0, 0);
+            else      rb[i] = load_rc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t % B_TPK) * 4, k0 + t / B_TPK + B_KPP * i, kend, p.kb_valid, b_cj, b_cc);
         }
     };
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     const bool do_rowsum = (AM == OP_RC) && p.rowsum_a && tile_n == 0;
-    auto store_tiles = [&](const float4 (&ra)[4], const float4 (&rb)[4], unsigned char* sA, unsigned char* sB) {
+    auto store_tiles = [&](const float4 (&ra)[A_PASS], const float4 (&rb)[B_PASS], unsigned char* sA, unsigned char* sB) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < A_PASS; ++i) {
             u32x2 hi, lo;
             if (AM == OP_RC && do_rowsum) { bsum[0] += ra[i].x; bsum[1] += ra[i].y; bsum[2] += ra[i].z; bsum[3] += ra[i].w; }
             split4<NSPLIT>(ra[i], hi, lo);
-            int off = A_KC ? kc_off((t >> 3) + 32 * i, (t & 7) * 4) : (((t >> 5) + 8 * i) * RC_STRIDE + (t & 31) * 4) * 2;
+            const int off = A_KC ? kc_off((t >> 3) + KC_RPP * i, (t & 7) * 4) : ((t / A_TPK + A_KPP * i) * A_RCS + (t % A_TPK) * 4) * 2;
             *reinterpret_cast<u32x2*>(sA + off) = hi;
             if (PARTS == 2) *reinterpret_cast<u32x2*>(sA + A_BYTES + off) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+            u32x2 hi, lo;
             split4<NSPLIT>(rb[i], hi, lo);
-            off = B_KC ? kc_off((t >> 3) + 32 * i, (t & 7) * 4) : (((t >> 5) + 8 * i) * RC_STRIDE + (t & 31) * 4) * 2;
+            const int off = B_KC ? kc_off((t >> 3) + KC_RPP * i, (t & 7) * 4) : ((t / B_TPK + B_KPP * i) * B_RCS + (t % B_TPK) * 4) * 2;
             *reinterpret_cast<u32x2*>(sB + off) = hi;
             if (PARTS == 2) *reinterpret_cast<u32x2*>(sB + B_BYTES + off) = lo;
         }
     };
     // MFMA operand fragment for the 16-row sub-tile starting at tile row `rbase`: lane holds [row l15][k 8g..8g+7]
-    auto frag = [&](const unsigned char* img, bool kc, int rbase) -> bf16x8_t {
+    auto frag = [&](const unsigned char* img, bool kc, int rcs, int rbase) -> bf16x8_t {
         if (kc) {
             int row = rbase + l15;
             return *reinterpret_cast<const bf16x8_t*>(img + row * 64 + ((g ^ swz_h(row)) << 4));
         } else {
             const int q = l15 >> 2, pp = l15 & 3;
-            s16x4 v0 = lds_read_tr16(img + ((8 * g + q) * RC_STRIDE + rbase + 4 * pp) * 2);
-            s16x4 v1 = lds_read_tr16(img + ((8 * g + 4 + q) * RC_STRIDE + rbase + 4 * pp) * 2);
+            s16x4 v0 = lds_read_tr16(img + ((8 * g + q) * rcs + rbase + 4 * pp) * 2);
+            s16x4 v1 = lds_read_tr16(img + ((8 * g + 4 + q) * rcs + rbase + 4 * pp) * 2);
             s16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             return __builtin_bit_cast(bf16x8_t, v);
         }
@@ -198,8 +216,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int s = 0; s < PARTS; ++s) {
-                af[i][s] = frag(sA + s * A_BYTES, A_KC, wm * 64 + i * 16);
-                bfr[i][s] = frag(sB + s * B_BYTES, B_KC, wn * 64 + i * 16);
+                af[i][s] = frag(sA + s * A_BYTES, A_KC, A_RCS, wm * 64 + i * 16);
+                bfr[i][s] = frag(sB + s * B_BYTES, B_KC, B_RCS, wn * 64 + i * 16);
             }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     // kt+2 into the register set that was drained one iteration ago, (2) multiplies tile kt from LDS stage kt%2 and, in
     // the shadow of those MFMAs, converts tile kt+1 (whose loads were issued an iteration ago) and writes it to the
     // other LDS stage.  Loads are issued unconditionally (clamped addresses) so the compiler's vmcnt counts are static.
-    float4 ra0[4], rb0[4], ra1[4], rb1[4];
+    float4 ra0[A_PASS], rb0[B_PASS], ra1[A_PASS], rb1[B_PASS];
     unsigned char* const s0A = smem;
     unsigned char* const s0B = smem + A_BYTES * PARTS;
     unsigned char* const s1A = smem + STAGE;
@@ -246,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         if (t < 128) red[t] = 0.f;
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) atomicAdd(&red[(t & 31) * 4 + c], bsum[c]);
+        for (int c = 0; c < 4; ++c) atomicAdd(&red[(t % A_TPK) * 4 + c], bsum[c]);
         __syncthreads();
         if (t < 128 && m0 + t < p.M) atomicAdd(p.rowsum_a + m0 + t, red[t]);
     }
@@ -353,9 +371,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // Host launcher / C ABI
 // ---------------------------------------------------------------------------------------------
 template <int AM, int BMODE>
-static void launch_split(const GemmParams& p, int nsplit, dim3 grid, hipStream_t s) {
-    if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3>), grid, dim3(256), 0, s, p);
-    else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1>), grid, dim3(256), 0, s, p);
+static void launch_split(const GemmParams& p, int nsplit, int wn, dim3 grid, hipStream_t s) {
+    if (wn == 4) {
+        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 4>), grid, dim3(512), 0, s, p);
+        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 4>), grid, dim3(512), 0, s, p);
+    } else {
+        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 2>), grid, dim3(256), 0, s, p);
+        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 2>), grid, dim3(256), 0, s, p);
+    }
 }
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -367,7 +390,7 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
                           const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale,
                           float alpha, int beta, int act,
                           float drop_p, unsigned int seed, unsigned int stream_id,
-                          int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, hipStream_t stream) {
+                          int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, int tile_wn, hipStream_t stream) {
     UNAST_REQUIRE(A && B && C, "unast_gemm: null operand");
     UNAST_REQUIRE(M > 0 && N > 0 && K > 0, "unast_gemm: bad dims M=%d N=%d K=%d", M, N, K);
     UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_gemm: nsplit must be 1 or 3");
@@ -390,7 +413,15 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     p.alpha = alpha; p.beta = beta; p.act = act;
     p.drop_thresh = drop_threshold(drop_p); p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     p.seed = seed; p.stream = stream_id;
-    p.tiles_m = (M + GBM - 1) / GBM; p.tiles_n = (N + GBN - 1) / GBN;
+    // tile width: 128x256 when N is wide enough and the grid still fills the chip; `tile_wn` (2/4) overrides, 0 = auto
+    int wn = tile_wn;
+    if (wn != 2 && wn != 4) {
+        // measured on MI355X (tools/bench_gemm2.py + bench.py): the 128x256 tile is 10-15 % faster on isolated large
+        // shapes but no faster inside the train step; the 128x128 tile stays the default.
+        wn = 2;
+    }
+    const int gbn = 64 * wn;
+    p.tiles_m = (M + GBM - 1) / GBM; p.tiles_n = (N + gbn - 1) / gbn;
     int ksteps = (K + GBK - 1) / GBK;
     if (splitk > ksteps) splitk = ksteps;
     int steps_per = (ksteps + splitk - 1) / splitk;
@@ -416,12 +447,12 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     if (b_mode == OP_RC_CONV_DGRAD) UNAST_REQUIRE(K == 5 * conv_cb, "unast_gemm: bad conv dgrad geometry");
     if (b_mode == OP_RC_CONV_WGRAD) UNAST_REQUIRE((conv_cb & 3) == 0 && N == 5 * conv_cb && K % p.T == 0, "unast_gemm: bad conv wgrad geometry");
     dim3 grid(p.tiles_m >= 8 ? ((p.tiles_m + 7) / 8) * 8 * p.tiles_n : p.tiles_m * p.tiles_n, splitk, 1);
-    if (a_mode == OP_KC && b_mode == OP_KC) launch_split<OP_KC, OP_KC>(p, nsplit, grid, stream);
-    else if (a_mode == OP_KC && b_mode == OP_RC) launch_split<OP_KC, OP_RC>(p, nsplit, grid, stream);
-    else if (a_mode == OP_RC && b_mode == OP_RC) launch_split<OP_RC, OP_RC>(p, nsplit, grid, stream);
-    else if (a_mode == OP_KC_CONV && b_mode == OP_KC) launch_split<OP_KC_CONV, OP_KC>(p, nsplit, grid, stream);
-    else if (a_mode == OP_KC_CONV && b_mode == OP_RC_CONV_DGRAD) launch_split<OP_KC_CONV, OP_RC_CONV_DGRAD>(p, nsplit, grid, stream);
-    else if (a_mode == OP_RC && b_mode == OP_RC_CONV_WGRAD) launch_split<OP_RC, OP_RC_CONV_WGRAD>(p, nsplit, grid, stream);
+    if (a_mode == OP_KC && b_mode == OP_KC) launch_split<OP_KC, OP_KC>(p, nsplit, wn, grid, stream);
+    else if (a_mode == OP_KC && b_mode == OP_RC) launch_split<OP_KC, OP_RC>(p, nsplit, wn, grid, stream);
+    else if (a_mode == OP_RC && b_mode == OP_RC) launch_split<OP_RC, OP_RC>(p, nsplit, wn, grid, stream);
+    else if (a_mode == OP_KC_CONV && b_mode == OP_KC) launch_split<OP_KC_CONV, OP_KC>(p, nsplit, wn, grid, stream);
+    else if (a_mode == OP_KC_CONV && b_mode == OP_RC_CONV_DGRAD) launch_split<OP_KC_CONV, OP_RC_CONV_DGRAD>(p, nsplit, wn, grid, stream);
+    else if (a_mode == OP_RC && b_mode == OP_RC_CONV_WGRAD) launch_split<OP_RC, OP_RC_CONV_WGRAD>(p, nsplit, wn, grid, stream);
     else return unast_set_error(UNAST_ERR_ARG, "unast_gemm: unsupported operand mode pair (%d,%d)", a_mode, b_mode);
     if (p.slab) {
         size_t work = (size_t)M * (p.ld_slab / 4);

@@ -27,7 +27,7 @@ def _f32(t, name):
 
 
 def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bias=None, R=None, ldr=0, G=None,
-         ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False, rowsum_a=None, kb_valid=0):
+         ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False, rowsum_a=None, kb_valid=0, tile_wn=0):
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (R, "R"), (G, "G")):
         _f32(t, n)
     ws, ws_n = None, 0
@@ -36,7 +36,7 @@ def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bia
         ws = torch.empty(ws_n, dtype=torch.float32, device=C.device)          # split-K partial slabs (caching allocator)
     check(lib().unast_gemm(a_mode, b_mode, nsplit or config.NSPLIT, _p(A), lda, _p(B), ldb, _p(C), ldc, M, N, K, kb_valid,
                            conv[0], conv[1], conv[2], conv[3], _p(bias), _p(R), ldr, _p(G), ldg, gate_scale,
-                           alpha, beta, act, drop_p, seed & 0xFFFFFFFF, stream_id, splitk, _p(ws), ws_n, _p(rowsum_a), _stream()), "unast_gemm")
+                           alpha, beta, act, drop_p, seed & 0xFFFFFFFF, stream_id, splitk, _p(ws), ws_n, _p(rowsum_a), tile_wn, _stream()), "unast_gemm")
 
 
 SPLITK_TARGET_BLOCKS = 320
