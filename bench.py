@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("UNAST_PREC", "bf16x3"), choices=["bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-ops", action="store_true", help="time every op family (adds event overhead; not for the headline number)")
+    ap.add_argument("--backend", default=os.environ.get("UNAST_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI) is the product path; gloo only rehearses the multi-rank logic on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -141,12 +144,17 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
     if a.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+    if a.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from unast_amd import config, ops, train, utils
     from unast_amd.configs import make_args
@@ -225,6 +233,7 @@ def main():
            "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16x3" if config.NSPLIT == 3 else "bf16", "data": "synthetic",
+           "dist_backend": (a.backend if world > 1 else None),
            "config": {"workload": "%s: full adversarial gen+disc train step (AE+SP+clip/AdamW, D step+clip/AdamW), per-GPU B=%d, T_text=%d, T_mel=%d, "
                                   "num_layers=%d, d=256, 4 heads, FFN 1024, 2x bi-LSTM(64) discriminator, dropout/noise/SpecAugment active" % (a.workload, B, Tt, Tm, L),
                       "global_batch": B * world, "parallelism": "dp%d" % world,
