@@ -1,0 +1,69 @@
+"""Rows f-1 / f-3 of SURVEY.md section 8: outer train loop (grad accumulation, LR schedule) and reference-layout checkpoints."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+D = torch.device("cuda:0")
+
+
+def small_args(**kw):
+    from unast_amd.configs import make_args
+    d = dict(num_layers=1, ae_steps=2, sp_steps=1, d_steps=1, cm_steps=0, epochs=2, epoch_steps=3, train_batch_size=2, warmup_steps=4, lr=0.05)
+    d.update(kw)
+    return make_args(**d)
+
+
+def test_train_loop_reduces_loss_and_follows_schedule(tmp_path):
+    from unast_amd import train, utils
+    train.DEVICE = D
+    utils.set_deterministic(False)
+    args = small_args(checkpoint_path=str(tmp_path / "ckpt"), epochs=3, epoch_steps=6)
+    lrs = []
+    model, hist = train.train(args, batch_getter=train.SyntheticBatchGetter(args, t_text=12, t_mel=32),
+                              on_epoch_end=lambda e, m, o, h: lrs.append(o.param_groups[0]["lr"]))
+    assert len(hist) == 3 and set(hist[0]) == {"t_ae", "s_ae", "d_ae", "asr_", "tts_", "sp_d", "d"}
+    assert hist[-1]["s_ae"] < hist[0]["s_ae"] and hist[-1]["tts_"] < hist[0]["tts_"]          # it learns something
+    exp = [args.lr * (min(s, 1e9) / 4 ** 1.5 if s < 4 else 1 / s ** 0.5) for s in (6, 12, 18)]
+    assert all(abs(a - b) < 1e-9 for a, b in zip(lrs, exp)), (lrs, exp)
+    assert os.path.isfile(tmp_path / "ckpt" / "model_most_recent.ckpt")
+
+
+def test_checkpoint_roundtrip_and_torch_adamw_format(tmp_path):
+    from collections import defaultdict
+    from unast_amd import train, utils
+    from unast_amd.checkpoint import save_ckp, load_ckp
+    from unast_amd.portable import synth_batch
+    train.DEVICE = D
+    utils.set_deterministic(True)
+    args = small_args(ae_steps=1)
+    batch = tuple(torch.from_numpy(x) for x in synth_batch(2, 12, 32, seed=5, ragged=True))
+    batches = dict(unsup=[batch], sup=[batch], disc=[batch])
+    utils.set_seed(3)
+    _, _, model, opt, _ = train.initialize_model(args)
+    opt.param_groups[0]["lr"] = 1e-3
+    train.train_step(defaultdict(list), model, opt, None, batches, 0, args)
+    save_ckp(0, 1.0, model, opt, True, str(tmp_path))
+    ck = torch.load(tmp_path / "model_best.ckpt", weights_only=False)
+    assert set(ck) == {"epoch", "valid_loss_min", "state_dict", "optimizer"} and ck["epoch"] == 1
+    # the optimizer entry must load into a stock torch.optim.AdamW over parameters of the reference shapes
+    ref_params = [torch.nn.Parameter(v.clone().float()) for k, v in ck["state_dict"].items()
+                  if v.dtype.is_floating_point and "running_" not in k and not k.endswith(".pe")]
+    topt = torch.optim.AdamW(ref_params, lr=1e-3, weight_decay=args.weight_decay)
+    topt.load_state_dict(ck["optimizer"])
+    assert len(topt.state) == len(ref_params) - 2                         # reduce_c_W.{weight,bias} never updated
+    i_conv = [k for k, v in ck["state_dict"].items() if v.dtype.is_floating_point and "running_" not in k and not k.endswith(".pe")].index("text_m.prenet.conv1.conv.weight")
+    assert tuple(topt.state[ref_params[i_conv]]["exp_avg"].shape) == (256, 256, 5)
+    # resume: a second step from the restored state equals a second step of the original run
+    train.train_step(defaultdict(list), model, opt, None, batches, 1, args)
+    after_orig = model._store().flat.detach().clone()
+    utils.set_seed(99)
+    _, _, model2, opt2, _ = train.initialize_model(args)
+    opt2.param_groups[0]["lr"] = 1e-3
+    ep, vl, model2, opt2 = load_ckp(str(tmp_path / "model_best.ckpt"), model2, opt2)
+    assert ep == 1 and vl == 1.0
+    train.train_step(defaultdict(list), model2, opt2, None, batches, 1, args)
+    diff = (model2._store().flat - after_orig).abs().max().item()
+    assert diff < 5e-5, diff        # bias-gradient atomics are order-nondeterministic (1e-7 relative); Adam normalises them up to ~3e-6
+    utils.set_deterministic(False)

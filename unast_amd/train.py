@@ -395,6 +395,75 @@ def train_step(losses, model, optimizer, scheduler, batches, step, args):
         scheduler.step()
 
 
+class SyntheticBatchGetter:
+    """Stand-in for BatchGetter (src/train.py:32-78): the reference iterates three DataLoaders over LJSpeech; the data
+    pipeline is out of scope, so batches here are synthetic with the collate contract
+    (text int64 [B,Tt] EOS-terminated and zero padded, mel float32 [B,Tm,80], lengths, sorted by text length)."""
+
+    def __init__(self, args, t_text=180, t_mel=800, ragged=True, seed=0):
+        self.B, self.Tt, self.Tm, self.ragged, self.seed, self.n = args.train_batch_size, t_text, t_mel, ragged, seed, 0
+
+    def _next(self):
+        from .portable import synth_batch
+        self.n += 1
+        return tuple(torch.from_numpy(x) for x in synth_batch(self.B, self.Tt, self.Tm, seed=self.seed + self.n, ragged=self.ragged))
+
+    get_supervised_batch = get_unsupervised_batch = get_discriminator_batch = _next
+
+
+def log_loss_metrics(losses, epoch, eval=False):
+    """src/train.py:756-764 (one host read per logged key, at the epoch boundary)."""
+    kind = "Eval_" if eval else "Train"
+    out = {k: float(torch.stack([torch.as_tensor(x, dtype=torch.float32).cpu() for x in v]).mean()) for k, v in losses.items() if len(v)}
+    print("{} epoch {:-3d} ".format(kind, epoch) + " ".join("%s %.4f" % kv for kv in sorted(out.items())))
+    return out
+
+
+def train(args, batch_getter=None, on_epoch_end=None):
+    """The hot loop of the reference's train() (src/train.py:567-696) without evaluation / TensorBoard / dataset code:
+    per outer step ae_steps x AE, sp_steps x SP (accumulated, scaled by 1/accum_steps), optimizer_step, then d_steps x D,
+    optimizer_step, scheduler.step().  Returns (model, per-epoch loss means)."""
+    set_seed(args.seed)
+    if getattr(args, "cm_steps", 0):
+        raise NotImplementedError("cm_steps > 0 (cross-model back-translation): SURVEY.md section 8f-2")
+    batch_getter = batch_getter or SyntheticBatchGetter(args)
+    s_epoch, best, model, optimizer, scheduler = initialize_model(args)
+    max_obj_steps = max(args.ae_steps, args.sp_steps, args.d_steps if args.use_discriminator else 0)
+    accum_steps = args.ae_steps + args.sp_steps
+    history = []
+    for epoch in range(s_epoch, args.epochs):
+        losses = defaultdict(list)
+        for s in range(args.epoch_steps):
+            model.train()
+            if args.use_discriminator:
+                freeze_model_parameters(model.discriminator)
+            for si in range(args.ae_steps):
+                step = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps + si
+                train_ae_step(losses, model, batch_getter.get_unsupervised_batch(), step, accum_steps, args)
+            for si in range(args.sp_steps):
+                step = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps + si
+                train_sp_step(losses, model, batch_getter.get_supervised_batch(), step, accum_steps, args)
+            optimizer_step(model, optimizer, args)
+            if args.use_discriminator:
+                unfreeze_model_parameters(model.discriminator)
+                for si in range(args.d_steps):
+                    step = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps + si
+                    train_discriminator_step(losses, model, batch_getter.get_discriminator_batch(), step, args.d_steps, args)
+                optimizer_step(model, optimizer, args)
+            if scheduler is not None:
+                scheduler.step()
+        history.append(log_loss_metrics(losses, epoch))
+        if not all(v == v and abs(v) < float("inf") for v in history[-1].values()):
+            raise RuntimeError("Loss is NaN")               # the reference's check_nan_loss, once per epoch instead of per sub-step
+        if getattr(args, "checkpoint_path", None):
+            from .checkpoint import save_ckp
+            save_ckp(epoch, 300.0, model, optimizer, False, args.checkpoint_path)
+        if on_epoch_end is not None:
+            on_epoch_end(epoch, model, optimizer, history[-1])
+    model.eval()
+    return model, history
+
+
 #####----- Model, optimizer, scheduler initializations -----#####
 def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, last_epoch=-1):
     """src/train.py:859-884."""
@@ -457,6 +526,59 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         self.model._store().zero_grad()
+
+    # ---- torch.optim.AdamW-compatible (de)serialisation (reference checkpoints: src/utils.py:139-195) ----------------
+    def _param_ranges(self, st):
+        """[(index, name, param, offset, numel, region_range)] in model.parameters() order (= torch's param indices)."""
+        out = []
+        names = {id(p): n for n, p in st.params.items()}
+        for i, p in enumerate(self.model.parameters()):
+            n = names[id(p)]
+            o = st.offsets[n]
+            rr = next((a, b) for (a, b) in st.regions.values() if a <= o < b)
+            out.append((i, n, p, o, p.numel(), rr))
+        return out
+
+    def state_dict(self):
+        st = self.model._store()
+        self._buffers(st)
+        state = {}
+        for i, n, p, o, k, rr in self._param_ranges(st):
+            steps = self._steps.get(rr, 0)
+            if steps == 0:
+                continue                                   # never updated (e.g. reduce_c_W): torch keeps no state either
+            m, v = self._m[o:o + k], self._v[o:o + k]
+            if n.endswith(".conv.weight"):                 # tap-major in HBM -> reference [Cout,Cin,5]
+                co, ci, ks = p.shape
+                m, v = m.view(co, ks, ci).permute(0, 2, 1), v.view(co, ks, ci).permute(0, 2, 1)
+            else:
+                m, v = m.view(p.shape), v.view(p.shape)
+            state[i] = {"step": torch.tensor(float(steps)), "exp_avg": m.detach().cpu().contiguous(), "exp_avg_sq": v.detach().cpu().contiguous()}
+        g = dict(self.param_groups[0])
+        g["params"] = list(range(len(list(self.model.parameters()))))
+        for key, val in (("amsgrad", False), ("maximize", False), ("foreach", None), ("capturable", False), ("differentiable", False), ("fused", None)):
+            g.setdefault(key, val)
+        return {"state": state, "param_groups": [g]}
+
+    def load_state_dict(self, sd):
+        st = self.model._store()
+        self._buffers(st)
+        self._m.zero_(); self._v.zero_()
+        self._steps = defaultdict(int)
+        for i, n, p, o, k, rr in self._param_ranges(st):
+            ent = sd["state"].get(i, sd["state"].get(str(i)))
+            if ent is None:
+                continue
+            m, v = ent["exp_avg"].to(self._m.device, torch.float32), ent["exp_avg_sq"].to(self._m.device, torch.float32)
+            if n.endswith(".conv.weight"):
+                m, v = m.permute(0, 2, 1), v.permute(0, 2, 1)
+            self._m[o:o + k].copy_(m.reshape(-1))
+            self._v[o:o + k].copy_(v.reshape(-1))
+            self._steps[rr] = max(self._steps[rr], int(float(ent["step"])))
+        g = sd["param_groups"][0]
+        for key in ("lr", "weight_decay", "betas", "eps", "initial_lr"):
+            if key in g:
+                self.param_groups[0][key] = tuple(g[key]) if key == "betas" else g[key]
 
     def grad_norm(self):
         """Pre-clip global gradient norm of the last step (one host read; for logging/tests)."""
