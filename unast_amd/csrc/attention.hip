@@ -13,6 +13,7 @@
 //   dK/dV kernel: S[q,key] = Q.K^T puts the KEY on the lane; P and dS accumulators are then the B operands of
 //   dV^T = dO^T.P and dK^T = Q^T.dS, with dO^T / Q^T read transposed from the same [q][d] LDS images that feed S, dP.
 #include "common.h"
+#include <type_traits>
 
 #define HD 64
 #define ALD 72                     // bf16 elements per LDS image row (64 + 8 pad) = 144 B
@@ -134,6 +135,8 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
                 const float* src = Qb + (size_t)q * p.ldq + 32 * kst + 8 * g;
                 a = *reinterpret_cast<const float4*>(src);
                 c = *reinterpret_cast<const float4*>(src + 4);
+                // scores are wanted in log2 units: fold scale*log2(e) into Q once instead of scaling every score
+                a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc; c.x *= sc; c.y *= sc; c.z *= sc; c.w *= sc;
             }
             bf16x8_t hi, lo;
             split8<NSPLIT>(a, c, hi, lo);
@@ -157,6 +160,12 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
         }
     }
 
+    uint32_t rkeys[2] = {0u, 0u};
+    if (p.drop_thresh) {
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+            rkeys[qs] = rng_row_key(p.seed, p.stream, (uint32_t)(((size_t)b * p.H + h) * p.Tq + q0 + 16 * qs + l15));
+    }
     float m[2] = {NEG_BIG, NEG_BIG}, lsum[2] = {0.f, 0.f};
     f32x4 o[4][2];
 #pragma unroll
@@ -200,62 +209,79 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
                 }
             }
         // ---- softmax (fwd: online; dQ: from saved LSE) ---------------------------------------------------
+        // Interior tiles (every key < klen and, if causal, below the diagonal for all 32 queries of this wave) take a
+        // path without per-element mask tests; the condition is wave-uniform.
+        const bool interior = (kt * 64 + 64 <= klen) && (!p.causal || kt * 64 + 63 <= q0) && (MODE == 0 || q0 + 31 < p.Tq);
+        auto softmax_tile = [&](auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
-            const int q = q0 + 16 * qs + l15;
-            const uint32_t rkey = p.drop_thresh ? rng_row_key(p.seed, p.stream, (uint32_t)(((size_t)b * p.H + h) * p.Tq + q)) : 0u;
-            float mref;
-            if (MODE == 0) {
-                float tmax = NEG_BIG;
+            for (int qs = 0; qs < 2; ++qs) {
+                const int q = q0 + 16 * qs + l15;
+                const uint32_t rkey = rkeys[qs];
+                float mref;
+                if (MODE == 0) {
+                    float tmax = NEG_BIG;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = s[ks][qs][r];
+                            if (MASKED) {
+                                const int key = kt * 64 + 16 * ks + 4 * g + r;
+                                const bool valid = key < klen && (!p.causal || key <= q);
+                                v = valid ? v : NEG_BIG;
+                                s[ks][qs][r] = v;
+                            }
+                            tmax = fmaxf(tmax, v);
+                        }
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                    const float mnew = fmaxf(m[qs], tmax);
+                    const float alpha = __builtin_amdgcn_exp2f(m[qs] - mnew);
+                    m[qs] = mnew;
+                    mref = mnew;
+                    lsum[qs] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) { o[dt][qs][0] *= alpha; o[dt][qs][1] *= alpha; o[dt][qs][2] *= alpha; o[dt][qs][3] *= alpha; }
+                } else {
+                    mref = lse2[qs];
+                }
+                float rs = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int key0 = kt * 64 + 16 * ks + 4 * g;
+                    uint32_t h01 = 0, h23 = 0;
+                    if (p.drop_thresh) { h01 = rng_pair(rkey, (uint32_t)key0); h23 = rng_pair(rkey, (uint32_t)key0 + 2u); }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int key = kt * 64 + 16 * ks + 4 * g + r;
-                        const bool valid = key < klen && (!p.causal || key <= q);
-                        const float v = valid ? s[ks][qs][r] * sc : NEG_BIG;
-                        s[ks][qs][r] = v;
-                        tmax = fmaxf(tmax, v);
-                    }
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                const float mnew = fmaxf(m[qs], tmax);
-                const float alpha = exp2f(m[qs] - mnew);
-                m[qs] = mnew;
-                mref = mnew;
-                lsum[qs] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) { o[dt][qs][0] *= alpha; o[dt][qs][1] *= alpha; o[dt][qs][2] *= alpha; o[dt][qs][3] *= alpha; }
-            } else {
-                mref = lse2[qs];
-            }
-            float rs = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 64 + 16 * ks + 4 * g + r;
-                    float pv;
-                    if (MODE == 0) {
-                        const float v = s[ks][qs][r];
-                        pv = (v > 0.5f * NEG_BIG) ? exp2f(v - mref) : 0.f;
-                        rs += pv;
-                        if (p.drop_thresh) pv = rng_keep(rkey, (uint32_t)key, p.drop_thresh) ? pv * p.drop_scale : 0.f;
-                        s[ks][qs][r] = pv;
-                    } else {
-                        const bool valid = key < klen && (!p.causal || key <= q) && q < p.Tq;
-                        pv = valid ? exp2f(s[ks][qs][r] * sc - mref) : 0.f;
-                        float dpe = dp[ks][qs][r];
-                        if (p.drop_thresh) dpe = rng_keep(rkey, (uint32_t)key, p.drop_thresh) ? dpe * p.drop_scale : 0.f;
-                        s[ks][qs][r] = pv * (dpe - delta[qs]);           // dS^T
+                        const uint32_t hh = (r < 2) ? h01 : h23;
+                        const bool keep = !p.drop_thresh || ((r & 1) ? rng_keep_hi(hh, p.drop_thresh) : rng_keep_lo(hh, p.drop_thresh));
+                        float pv;
+                        if (MODE == 0) {
+                            const float v = s[ks][qs][r];
+                            pv = __builtin_amdgcn_exp2f(v - mref);            // masked entries: exp2(-1e30 - m) = 0
+                            rs += pv;
+                            s[ks][qs][r] = keep ? pv * p.drop_scale : 0.f;
+                        } else {
+                            pv = __builtin_amdgcn_exp2f(s[ks][qs][r] - mref);
+                            if (MASKED) {
+                                const int key = key0 + r;
+                                const bool valid = key < klen && (!p.causal || key <= q) && q < p.Tq;
+                                pv = valid ? pv : 0.f;
+                            }
+                            const float dpe = keep ? dp[ks][qs][r] * p.drop_scale : 0.f;
+                            s[ks][qs][r] = pv * (dpe - delta[qs]);           // dS^T
+                        }
                     }
                 }
-            if (MODE == 0) {
-                rs += __shfl_xor(rs, 16, 64);
-                rs += __shfl_xor(rs, 32, 64);
-                lsum[qs] += rs;
+                if (MODE == 0) {
+                    rs += __shfl_xor(rs, 16, 64);
+                    rs += __shfl_xor(rs, 32, 64);
+                    lsum[qs] += rs;
+                }
             }
-        }
+        };
+        if (interior) softmax_tile(std::false_type{}); else softmax_tile(std::true_type{});
         // ---- O^T += V^T . P^T   (dQ mode: dQ^T += K^T . dS^T) ---------------------------------------------
         unsigned char* const* sX = (MODE == 0) ? sV : sK;
 #pragma unroll
@@ -346,6 +372,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) { dk[dt][ks] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][ks] = dk[dt][ks]; }
 
+    const uint32_t rbase = pcg_hash(p.stream + pcg_hash(p.seed));      // rng_row_key(seed, stream, row) = pcg(row + rbase)
     const bool block_live = kblk < klen;                    // all keys of the block masked -> gradients are zero
     const int qt_begin = p.causal ? (kblk / 32) : 0;
     const int qt_end = block_live ? (p.Tq + 31) / 32 : qt_begin;
@@ -384,30 +411,39 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
                 }
             }
         // ---- P (dropped) and dS; lane: key = k0+16ks+l15, q = 32qt+16qs+4g+r ------------------------------
+        // interior (wave-uniform): every (query, key) pair of this 32x32 sub-problem is unmasked
+        const bool interior = (qt * 32 + 32 <= p.Tq) && (k0 + 32 <= klen) && (!p.causal || k0 + 31 <= qt * 32);
+        auto pointwise = [&](auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs)
+            for (int qs = 0; qs < 2; ++qs)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = qt * 32 + 16 * qs + 4 * g + r;
-                const bool qok = q < p.Tq;
-                const float l2 = qok ? lseb[q] * LOG2E : 0.f;
-                const float de = qok ? delb[q] : 0.f;
-                const uint32_t rkey = p.drop_thresh ? rng_row_key(p.seed, p.stream, (uint32_t)(((size_t)b * p.H + h) * p.Tq + q)) : 0u;
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qt * 32 + 16 * qs + 4 * g + r;
+                    const bool qok = !MASKED || q < p.Tq;
+                    const float l2 = qok ? lseb[q] * LOG2E : 0.f;
+                    const float de = qok ? delb[q] : 0.f;
+                    const uint32_t rkey = p.drop_thresh ? pcg_hash((uint32_t)(((size_t)b * p.H + h) * p.Tq + q) + rbase) : 0u;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int key = k0 + 16 * ks + l15;
-                    const bool valid = qok && key < klen && (!p.causal || key <= q);
-                    const float pv = valid ? exp2f(s[qs][ks][r] * sc - l2) : 0.f;
-                    float pd = pv, dpe = dp[qs][ks][r];
-                    if (p.drop_thresh) {
-                        const bool keep = rng_keep(rkey, (uint32_t)key, p.drop_thresh);
-                        pd = keep ? pv * p.drop_scale : 0.f;
-                        dpe = keep ? dpe * p.drop_scale : 0.f;
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int key = k0 + 16 * ks + l15;
+                        float pv = __builtin_amdgcn_exp2f(s[qs][ks][r] * sc - l2);
+                        if (MASKED) {
+                            const bool valid = qok && key < klen && (!p.causal || key <= q);
+                            pv = valid ? pv : 0.f;
+                        }
+                        float pd = pv, dpe = dp[qs][ks][r];
+                        if (p.drop_thresh) {
+                            const bool keep = rng_keep(rkey, (uint32_t)key, p.drop_thresh);
+                            pd = keep ? pv * p.drop_scale : 0.f;
+                            dpe = keep ? dpe * p.drop_scale : 0.f;
+                        }
+                        s[qs][ks][r] = pd;                       // dropped probabilities (B operand of dV)
+                        dp[qs][ks][r] = pv * (dpe - de);         // dS (B operand of dK)
                     }
-                    s[qs][ks][r] = pd;                       // dropped probabilities (B operand of dV)
-                    dp[qs][ks][r] = pv * (dpe - de);         // dS (B operand of dK)
                 }
-            }
+        };
+        if (interior) pointwise(std::false_type{}); else pointwise(std::true_type{});
         // ---- dV^T += dO^T . Pd ;  dK^T += Q^T . dS  (sum over the 32 queries of the tile) ------------------
         bf16x8_t pf[2][PARTS], sf[2][PARTS];
 #pragma unroll

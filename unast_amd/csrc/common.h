@@ -39,14 +39,23 @@ __device__ __forceinline__ uint32_t rng_row_key(uint32_t seed, uint32_t stream, 
     return pcg_hash(row + pcg_hash(stream + pcg_hash(seed)));
 }
 __device__ __forceinline__ uint32_t rng_u32(uint32_t row_key, uint32_t col) { return pcg_hash(col ^ row_key) ; }
-// keep decision for drop probability p encoded as threshold = p * 2^32 (0 => keep everything)
+// Keep decisions for dropout: ONE multiply-xorshift hash serves a pair of adjacent columns (16 bits each), keyed by the
+// already well-mixed per-row key.  thresh = p * 2^16 (0 => keep everything).  All kernels (GEMM epilogue, LayerNorm
+// backward, attention forward/backward, element-wise) use these two helpers, so masks agree across passes.
+__device__ __forceinline__ uint32_t rng_pair(uint32_t row_key, uint32_t col) {
+    uint32_t h = ((col >> 1) ^ row_key) * 0x9E3779B1u;
+    return h ^ (h >> 15);
+}
+__device__ __forceinline__ bool rng_keep_lo(uint32_t pair_hash, uint32_t thresh) { return (pair_hash & 0xFFFFu) >= thresh; }
+__device__ __forceinline__ bool rng_keep_hi(uint32_t pair_hash, uint32_t thresh) { return (pair_hash >> 16) >= thresh; }
 __device__ __forceinline__ bool rng_keep(uint32_t row_key, uint32_t col, uint32_t thresh) {
-    return rng_u32(row_key, col) >= thresh;
+    const uint32_t h = rng_pair(row_key, col);
+    return ((col & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thresh;
 }
 static inline uint32_t drop_threshold(float p) {
     if (p <= 0.f) return 0u;
-    double t = (double)p * 4294967296.0;
-    if (t > 4294967295.0) t = 4294967295.0;
+    double t = (double)p * 65536.0 + 0.5;
+    if (t > 65535.0) t = 65535.0;
     return (uint32_t)t;
 }
 

@@ -15,7 +15,13 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (raw getter: ~0.3 us instead of ~9 us)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -375,7 +375,8 @@ def unfreeze_model_parameters(model):
 def train_step(losses, model, optimizer, scheduler, batches, step, args):
     """One iteration of the hot loop of train() (src/train.py:602-655) with cm_steps = 0.
     `batches` = dict(unsup=[...ae_steps batches], sup=[...sp_steps], disc=[...d_steps])."""
-    model.train()
+    if not model.training:
+        model.train()
     if args.use_discriminator:
         freeze_model_parameters(model.discriminator)
     accum_steps = args.ae_steps + getattr(args, "cm_steps", 0) + args.sp_steps
