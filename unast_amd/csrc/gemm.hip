@@ -95,12 +95,13 @@ __device__ __forceinline__ float4 load_rc(const GemmParams& p, const float* __re
     return v;
 }
 
-template <int AM, int BMODE, int NSPLIT, int WN>
-__global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_kernel(const GemmParams p) {
+template <int AM, int BMODE, int NSPLIT, int WN, int WM>
+__global__ __launch_bounds__(64 * WM * WN, (WM == 4 ? 4 : 2)) void gemm_kernel(const GemmParams p) {
     constexpr bool A_KC = (AM == OP_KC || AM == OP_KC_CONV);
     constexpr bool B_KC = (BMODE == OP_KC);
     constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
-    constexpr int NT = 128 * WN;                       // threads
+    constexpr int NT = 64 * WM * WN;                   // threads
+    constexpr int MI = 8 / WM;                         // 16-row sub-tiles per wave along M (wave tile = 16*MI x 64)
     constexpr int GBN = 64 * WN;                       // block tile columns
     constexpr int A_BYTES = A_KC ? kc_bytes(GBM) : rc_bytes(GBM);
     constexpr int B_BYTES = B_KC ? kc_bytes(GBN) : rc_bytes(GBN);
@@ -204,23 +205,23 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_kernel(const
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](const unsigned char* sA, const unsigned char* sB) {
-        bf16x8_t af[4][PARTS], bfr[4][PARTS];
+        bf16x8_t af[MI][PARTS], bfr[4][PARTS];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int s = 0; s < PARTS; ++s) {
 #pragma unroll
-            for (int s = 0; s < PARTS; ++s) {
-                af[i][s] = frag(sA + s * A_BYTES, A_KC, A_RCS, wm * 64 + i * 16);
-                bfr[i][s] = frag(sB + s * B_BYTES, B_KC, B_RCS, wn * 64 + i * 16);
-            }
+            for (int i = 0; i < MI; ++i) af[i][s] = frag(sA + s * A_BYTES, A_KC, A_RCS, wm * (16 * MI) + i * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) bfr[i][s] = frag(sB + s * B_BYTES, B_KC, B_RCS, wn * 64 + i * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // swapped operands: the B tile is the MFMA "A" (rows = n), so each lane ends up with 4 consecutive n
@@ -273,8 +274,8 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_kernel(const
     if (p.slab) {                                   // split-K: raw partial sums to this split's slab (plain 16-B stores)
         float* slab = p.slab + (size_t)blockIdx.y * p.slab_stride;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + l15;
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (16 * MI) + i * 16 + l15;
             if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -297,8 +298,8 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_kernel(const
         for (int r = 0; r < 4; ++r) bias_v[j][r] = (p.bias && first_split && n + r < p.N) ? p.bias[n + r] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + l15;
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (16 * MI) + i * 16 + l15;
         if (m >= p.M) continue;
         uint32_t rkey = 0;
         if (p.drop_thresh) rkey = rng_row_key(p.seed, p.stream, (uint32_t)m);
@@ -373,11 +374,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <int AM, int BMODE>
 static void launch_split(const GemmParams& p, int nsplit, int wn, dim3 grid, hipStream_t s) {
     if (wn == 4) {
-        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 4>), grid, dim3(512), 0, s, p);
-        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 4>), grid, dim3(512), 0, s, p);
+        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 4, 2>), grid, dim3(512), 0, s, p);
+        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 4, 2>), grid, dim3(512), 0, s, p);
+    } else if (wn == 8) {      // 128x128 tile, 8 waves (4 along M x 2 along N): <=128 VGPRs, 4 waves/SIMD
+        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 2, 4>), grid, dim3(512), 0, s, p);
+        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 2, 4>), grid, dim3(512), 0, s, p);
     } else {
-        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 2>), grid, dim3(256), 0, s, p);
-        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 2>), grid, dim3(256), 0, s, p);
+        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 2, 2>), grid, dim3(256), 0, s, p);
+        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 2, 2>), grid, dim3(256), 0, s, p);
     }
 }
 
@@ -415,12 +419,13 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     p.seed = seed; p.stream = stream_id;
     // tile width: 128x256 when N is wide enough and the grid still fills the chip; `tile_wn` (2/4) overrides, 0 = auto
     int wn = tile_wn;
-    if (wn != 2 && wn != 4) {
-        // measured on MI355X (tools/bench_gemm2.py + bench.py): the 128x256 tile is 10-15 % faster on isolated large
-        // shapes but no faster inside the train step; the 128x128 tile stays the default.
-        wn = 2;
+    if (wn != 2 && wn != 4 && wn != 8) {
+        // measured on MI355X (tools/bench_gemm2.py): for forward / dgrad shapes the 128x128 tile shared by 8 waves
+        // (<=128 VGPRs, 4 waves/SIMD) is 10-25 % faster than 4 waves (more waves to cover LDS/barrier/global latencies);
+        // weight gradients (long K, split-K) are equal, the 128x256 tile only helps isolated large shapes.
+        wn = (a_mode == OP_RC) ? 2 : 8;
     }
-    const int gbn = 64 * wn;
+    const int gbn = (wn == 4) ? 256 : 128;
     p.tiles_m = (M + GBM - 1) / GBM; p.tiles_n = (N + gbn - 1) / gbn;
     int ksteps = (K + GBK - 1) / GBK;
     if (splitk > ksteps) splitk = ksteps;
