@@ -246,7 +246,11 @@ class Model:
     # -- discriminator (src/network.py:172-186, src/module.py:297-336) ------------------------
     def lstm_discriminator(self, x, lens, hid=64, layers=2):
         """Packed bi-LSTM: only steps t < lens[b] are processed; gate order i,f,g,o; the reverse
-        direction starts at t = lens[b]-1.  Output: fc2(leaky_relu(reduce_h_W([h_fwd,h_bwd]) of top layer))."""
+        direction starts at t = lens[b]-1.  Output: fc2(leaky_relu(reduce_h_W([h_fwd,h_bwd]) of top layer)).
+        With self.packed_lstm = True the recurrence runs through torch's own packed-sequence LSTM (what the reference
+        calls, src/module.py:306,315-316) instead of the explicit time loop below; tests pin the two against each other."""
+        if getattr(self, "packed_lstm", False):
+            return self._lstm_discriminator_packed(x, lens, hid, layers)
         P = self.P
         B, T, _ = x.shape
         valid = lens_mask(lens, T).float().unsqueeze(-1)
@@ -279,6 +283,27 @@ class Model:
         new_h = linear(hcat, P["discriminator.rnn.reduce_h_W.weight"], P["discriminator.rnn.reduce_h_W.bias"])
         a = torch.nn.functional.leaky_relu(new_h, 0.2)
         return linear(a, P["discriminator.fc2.weight"], P["discriminator.fc2.bias"]).squeeze(-1)
+
+
+def _lstm_discriminator_packed(self, x, lens, hid=64, layers=2):
+    P = self.P
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, lens.cpu(), batch_first=True, enforce_sorted=False)
+    flat = []
+    for l in range(layers):
+        for suf in ("", "_reverse"):
+            flat += [P["discriminator.rnn.rnn.%s_l%d%s" % (k, l, suf)] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    B = x.shape[0]
+    h0 = torch.zeros(layers * 2, B, hid)
+    out, hn, cn = torch._VF.lstm(packed.data, packed.batch_sizes, (h0, h0.clone()), flat, True, layers, 0.0, False, True)
+    hn = hn[:, packed.unsorted_indices] if packed.unsorted_indices is not None else hn
+    h = hn.view(layers, 2, B, hid)
+    hcat = torch.cat((h[-1, 0], h[-1, 1]), dim=-1)
+    new_h = linear(hcat, P["discriminator.rnn.reduce_h_W.weight"], P["discriminator.rnn.reduce_h_W.bias"])
+    a = torch.nn.functional.leaky_relu(new_h, 0.2)
+    return linear(a, P["discriminator.fc2.weight"], P["discriminator.fc2.bias"]).squeeze(-1)
+
+
+Model._lstm_discriminator_packed = _lstm_discriminator_packed
 
 
 # ---- losses (src/train.py:100-122, 147-164) ---------------------------------------------------

@@ -122,3 +122,23 @@ def test_full_step_matches_reference(golden_dir, name):
         well = (g["gen_grad_norms"] > 1e-4 * g["gen_grad_norm"]) | (g["d_grad_norms"] > 1e-4 * g["d_grad_norm"])
         assert np.allclose(dd[well], tot[well], rtol=1e-2, atol=1e-7)
         assert np.array_equal(dd == 0, tot == 0), "set of untouched parameters differs (reduce_c_W must not move)"
+
+
+def test_packed_lstm_form_equals_time_loop():
+    """The oracle's two forms of the LSTM discriminator (explicit loop / torch packed-sequence LSTM) agree, values and grads."""
+    torch.manual_seed(1)
+    sd = state_dict_for(1)
+    x = torch.randn(5, 19, 256)
+    lens = torch.tensor([19, 3, 11, 1, 7])
+    outs, grads = [], []
+    for packed in (False, True):
+        m = R.Model(sd, 1)
+        m.packed_lstm = packed
+        y = m.lstm_discriminator(x, lens)
+        (y * torch.arange(1, 6)).sum().backward()
+        outs.append(y.detach())
+        grads.append({k: p.grad.clone() for k, p in m.P.items() if p.grad is not None})
+    assert torch.allclose(outs[0], outs[1], atol=1e-6)
+    assert grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        assert torch.allclose(grads[0][k], grads[1][k], atol=2e-6, rtol=1e-4), k
