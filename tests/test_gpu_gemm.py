@@ -18,7 +18,7 @@ TOL = {3: 3e-5, 1: 2e-2}
 
 @pytest.mark.parametrize("nsplit", [3, 1])
 @pytest.mark.parametrize("M,N,K", [(200, 256, 256), (333, 81, 256), (128, 1024, 256), (77, 256, 1024), (513, 46, 256),
-                                   (40, 256, 80)])
+                                   (40, 256, 80), (3000, 1024, 256), (2500, 1100, 64)])
 def test_linear_fwd_dgrad_wgrad(nsplit, M, N, K):
     from unast_amd import ops, config
     config.NSPLIT = nsplit

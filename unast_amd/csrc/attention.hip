@@ -95,9 +95,22 @@ __device__ __forceinline__ void tile_store(const float4 (&r)[NROWS / 16], unsign
     }
 }
 
+// XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so with the natural
+// (x fastest) order the nx blocks that sweep the SAME (batch, head) K/V (or Q/dO) land on nx different L2s and each one
+// re-fetches it from HBM (measured: FETCH_SIZE 2.3x the algorithmic bytes).  Here all nx blocks of one (b,h) get linear
+// ids that are equal mod 8.  Placement is a speed matter only; the grid is padded to a multiple of 8 (b,h) groups.
+__device__ __forceinline__ bool xcd_remap(int nx, int nbh, int& x, int& bh) {
+    const int L = blockIdx.x;
+    const int g = L & 7, s = L >> 3;
+    bh = (s / nx) * 8 + g;
+    x = s % nx;
+    return bh < nbh;
+}
+static inline unsigned xcd_grid(int nx, int nbh) { return (unsigned)(((nbh + 7) / 8) * 8 * nx); }
+
 // ------------------------------------------------------------------------------------------------------------
 // MODE 0: forward (O, LSE).  MODE 1: dQ (recomputes P from LSE; dQ = scale * dS.K).
-// grid (ceil(Tq/128), H, B), 256 threads; wave w owns queries [128*bx + 32w, +32).
+// 1-D grid of ceil(Tq/128) * B*H workgroups (XCD-remapped), 256 threads; wave w owns queries [128*bx + 32w, +32).
 // ------------------------------------------------------------------------------------------------------------
 template <int NSPLIT, int MODE>
 __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
@@ -108,8 +121,10 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
     unsigned char* sV[2] = {smem + PARTS * IMG, smem + PARTS * IMG + (PARTS - 1) * IMG};
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int qblk = blockIdx.x * 128;
+    int bx, bh;
+    if (!xcd_remap((p.Tq + 127) / 128, p.B * p.H, bx, bh)) return;       // whole workgroup exits (EXEC stays full elsewhere)
+    const int h = bh % p.H, b = bh / p.H;
+    const int qblk = bx * 128;
     const int q0 = qblk + wave * 32;
     const int klen = p.lens_k ? min(p.Tk, p.lens_k[b]) : p.Tk;
     int kmax = klen;
@@ -332,8 +347,10 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
     unsigned char* sD[2] = {smem + PARTS * IMG, smem + PARTS * IMG + (PARTS - 1) * IMG};
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int kblk = blockIdx.x * 128;
+    int bx, bh;
+    if (!xcd_remap((p.Tk + 127) / 128, p.B * p.H, bx, bh)) return;
+    const int h = bh % p.H, b = bh / p.H;
+    const int kblk = bx * 128;
     const int k0 = kblk + wave * 32;
     const int klen = p.lens_k ? min(p.Tk, p.lens_k[b]) : p.Tk;
     const float sc = p.scale * LOG2E;
@@ -532,7 +549,7 @@ extern "C" int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* 
     UNAST_REQUIRE(O && LSE && al16(O) && (ldo & 3) == 0, "unast_attn_fwd: bad output");
     UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_attn_fwd: nsplit must be 1 or 3");
     p.O = O; p.ldo = ldo; p.LSE = LSE;
-    dim3 grid((Tq + 127) / 128, H, B);
+    dim3 grid(xcd_grid((Tq + 127) / 128, B * H));
     if (nsplit == 3) hipLaunchKernelGGL((attn_q_kernel<3, 0>), grid, dim3(256), 0, stream, p);
     else             hipLaunchKernelGGL((attn_q_kernel<1, 0>), grid, dim3(256), 0, stream, p);
     return unast_check_launch("unast_attn_fwd");
@@ -553,7 +570,7 @@ extern "C" int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* 
     hipLaunchKernelGGL(attn_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, dO, lddo, O, ldo, delta_ws, rows, Tq, H);
     p.dO = dO; p.lddo = lddo; p.LSE = const_cast<float*>(LSE); p.Delta = delta_ws;
     p.O = dQ; p.ldo = lddq; p.dK = dK; p.dV = dV; p.lddk = lddk; p.lddv = lddv;
-    dim3 gq((Tq + 127) / 128, H, B), gk((Tk + 127) / 128, H, B);
+    dim3 gq(xcd_grid((Tq + 127) / 128, B * H)), gk(xcd_grid((Tk + 127) / 128, B * H));
     if (nsplit == 3) {
         hipLaunchKernelGGL((attn_q_kernel<3, 1>), gq, dim3(256), 0, stream, p);
         hipLaunchKernelGGL((attn_dkv_kernel<3>), gk, dim3(256), 0, stream, p);

@@ -33,7 +33,7 @@ struct GemmParams {
     const float* bias; const float* R; int ldr; const float* G; int ldg; float gate_scale;
     float alpha; int beta; int act;
     uint32_t drop_thresh; float drop_scale; uint32_t seed, stream;
-    int kchunk; int atomic; int tiles_m, tiles_n;
+    int kchunk; int atomic; int tiles_m, tiles_n, nsplitk;
     float* slab; int ld_slab; size_t slab_stride;     // split-K partial slabs [z][M][ld_slab]
     int kb_valid;                                     // rows of a row-contiguous B that exist (K may be zero-padded above it)
     float* rowsum_a;                                  // optional: rowsum_a[m] += sum_k A[m][k] (bias gradient fused into wgrad)
@@ -116,19 +116,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 ? 4 : 2)) void gemm_kernel(c
 
     // XCD-aware tile mapping: blocks b and b+8 (same XCD under round-robin dispatch) share the A row panel.
     const int pid = blockIdx.x;
-    int tile_m, tile_n;
-    if (p.tiles_m >= 8) {
+    int tile_m, tile_n, zsplit = 0;
+    if (p.tiles_m >= 8 && p.nsplitk == 1) {
         const int G = 8 * p.tiles_n;
         const int grp = pid / G, rem = pid - grp * G;
         tile_m = grp * 8 + (rem & 7);
         tile_n = rem >> 3;
-    } else {                                // few row panels (weight gradients): plain map, every XCD gets work
-        tile_m = pid % p.tiles_m;
-        tile_n = pid / p.tiles_m;
+    } else {
+        // few row panels (weight gradients, split-K): all tiles of one K-slice read the same operand rows, so they get
+        // linear ids that are equal mod 8 (same XCD / L2 under round-robin dispatch); grid padded to 8 slices.
+        const int ntile = p.tiles_m * p.tiles_n;
+        const int g8 = pid & 7, sidx = pid >> 3;
+        zsplit = (sidx / ntile) * 8 + g8;
+        const int tile = sidx % ntile;
+        tile_m = tile % p.tiles_m;
+        tile_n = tile / p.tiles_m;
+        if (zsplit >= p.nsplitk) return;
     }
     if (tile_m >= p.tiles_m) return;        // whole block exits together (keeps EXEC full for tr reads)
     const int m0 = tile_m * GBM, n0 = tile_n * GBN;
-    const int kbeg = blockIdx.y * p.kchunk;
+    const int kbeg = zsplit * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nk = (kend - kbeg + GBK - 1) / GBK;
 
@@ -270,9 +277,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 ? 4 : 2)) void gemm_kernel(c
         if (t < 128 && m0 + t < p.M) atomicAdd(p.rowsum_a + m0 + t, red[t]);
     }
     // ---- epilogue: lane holds C[m = ..+l15][n = ..+4g .. 4g+3] --------------------------------------
-    const bool first_split = (blockIdx.y == 0);
+    const bool first_split = (zsplit == 0);
     if (p.slab) {                                   // split-K: raw partial sums to this split's slab (plain 16-B stores)
-        float* slab = p.slab + (size_t)blockIdx.y * p.slab_stride;
+        float* slab = p.slab + (size_t)zsplit * p.slab_stride;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + wm * (16 * MI) + i * 16 + l15;
@@ -451,7 +458,8 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     if (a_mode == OP_KC_CONV) UNAST_REQUIRE((conv_ca & 3) == 0 && K == 5 * conv_ca && M % p.T == 0, "unast_gemm: bad conv A geometry");
     if (b_mode == OP_RC_CONV_DGRAD) UNAST_REQUIRE(K == 5 * conv_cb, "unast_gemm: bad conv dgrad geometry");
     if (b_mode == OP_RC_CONV_WGRAD) UNAST_REQUIRE((conv_cb & 3) == 0 && N == 5 * conv_cb && K % p.T == 0, "unast_gemm: bad conv wgrad geometry");
-    dim3 grid(p.tiles_m >= 8 ? ((p.tiles_m + 7) / 8) * 8 * p.tiles_n : p.tiles_m * p.tiles_n, splitk, 1);
+    p.nsplitk = splitk;
+    dim3 grid((p.tiles_m >= 8 && splitk == 1) ? ((p.tiles_m + 7) / 8) * 8 * p.tiles_n : ((splitk + 7) / 8) * 8 * p.tiles_m * p.tiles_n, 1, 1);
     if (a_mode == OP_KC && b_mode == OP_KC) launch_split<OP_KC, OP_KC>(p, nsplit, wn, grid, stream);
     else if (a_mode == OP_KC && b_mode == OP_RC) launch_split<OP_KC, OP_RC>(p, nsplit, wn, grid, stream);
     else if (a_mode == OP_RC && b_mode == OP_RC) launch_split<OP_RC, OP_RC>(p, nsplit, wn, grid, stream);
