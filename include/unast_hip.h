@@ -111,6 +111,10 @@ int unast_rowmask(const float* x, float* y, int rows, int D, float p, unsigned i
                   hipStream_t stream);
 /* a += b : gradient accumulation for activations consumed by several ops (autograd's implicit add). */
 int unast_add_inplace(float* a, const float* b, int64_t n, hipStream_t stream);
+/* Autoregressive inference helpers (TextTransformer/SpeechTransformer.infer_sequence, src/network.py:219-252, 455-481):
+ * first-maximum argmax per row of the logits, and zeroing of generated frames/tokens at t >= lens[b] (int64 lengths). */
+int unast_argmax_rows(const float* x, int ld, int rows, int cols, int64_t* out, hipStream_t stream);
+int unast_mask_by_len(float* x, const int64_t* lens, int B, int T, int D, hipStream_t stream);
 /* a *= alpha: averaging of all-reduced gradients across data-parallel ranks (new vs. the single-device reference). */
 int unast_scale_inplace(float* a, float alpha, int64_t n, hipStream_t stream);
 /* dst[:, :cols] += src[:, :cols] with independent row strides (autograd's add for padded gradient buffers). */

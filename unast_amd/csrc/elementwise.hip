@@ -237,9 +237,45 @@ __global__ __launch_bounds__(256) void disc_scatter_kernel(const float* __restri
     }
 }
 
+// Row argmax (first maximum, as torch.argmax) for the autoregressive text decoder (src/network.py:466); one thread per row.
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int ld, int rows, int cols, int64_t* __restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * ld;
+    float best = xr[0];
+    int bi = 0;
+    for (int c = 1; c < cols; ++c) {
+        const float v = xr[c];
+        if (v > best) { best = v; bi = c; }
+    }
+    out[r] = bi;
+}
+
+// x[b, t, :] = 0 for t >= lens[b]  (pad masking of generated sequences, src/network.py:245-251, 476-480)
+__global__ __launch_bounds__(256) void mask_by_len_kernel(float* __restrict__ x, const int64_t* __restrict__ lens, int T, int D, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / D;
+        const int b = (int)(row / T), t = (int)(row - (size_t)b * T);
+        if (t >= lens[b]) x[i] = 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------
+extern "C" int unast_argmax_rows(const float* x, int ld, int rows, int cols, int64_t* out, hipStream_t stream) {
+    UNAST_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "unast_argmax_rows: bad arguments");
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, x, ld, rows, cols, out);
+    return unast_check_launch("unast_argmax_rows");
+}
+
+extern "C" int unast_mask_by_len(float* x, const int64_t* lens, int B, int T, int D, hipStream_t stream) {
+    UNAST_REQUIRE(x && lens && B > 0 && T > 0 && D > 0, "unast_mask_by_len: bad arguments");
+    const size_t total = (size_t)B * T * D;
+    hipLaunchKernelGGL(mask_by_len_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, x, lens, T, D, total);
+    return unast_check_launch("unast_mask_by_len");
+}
+
 extern "C" int unast_embed_fwd(const int64_t* ids, const float* E, float* out, int rows, int T, int D, int shift_sos,
                                float drop_p, unsigned int seed, unsigned int stream_id, float noise_p, unsigned int noise_stream,
                                hipStream_t stream) {

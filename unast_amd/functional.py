@@ -556,3 +556,36 @@ def lstm_discriminator(cx, tape, m, x, lens, Bd, T, need_input_grad=True):
                     acc(x, dxin)
         tape.record(bwd)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Inference-only helpers used by unast_amd.inference (no tape)
+# ---------------------------------------------------------------------------------------------------------------
+def speech_prenet_step(cx, m, frame2d):
+    """SpeechPrenet on [B, num_mels] rows (one decoder input position per sequence)."""
+    a = m.args
+    N = frame2d.shape[0]
+    W1, b1 = cx.P["speech_m.prenet.layer.fc1.linear_layer.weight"], cx.P["speech_m.prenet.layer.fc1.linear_layer.bias"]
+    W2, b2 = cx.P["speech_m.prenet.layer.fc2.linear_layer.weight"], cx.P["speech_m.prenet.layer.fc2.linear_layer.bias"]
+    h1 = _empty(N, W1.shape[0], like=frame2d)
+    ops.linear_fwd(frame2d, W1, b1, h1, act=1, drop_p=cx.p(a.s_pre_drop), seed=cx.seed, stream_id=cx.stream())
+    h2 = _empty(N, W2.shape[0], like=frame2d)
+    ops.linear_fwd(h1, W2, b2, h2, act=1)
+    return h2
+
+
+def speech_postnet_residual(cx, m, mel3d):
+    """mel + SpeechPostnet(mel) for a [B,T,M] tensor (src/network.py:246; BN in the model's current mode)."""
+    B, T, M = mel3d.shape
+    a = m.args
+    N = B * T
+    x = Var(mel3d.reshape(N, M))
+    y = conv_bn_act(cx, None, x, B, T, "speech_m.postnet.conv1.", "speech_m.postnet.pre_batchnorm.", 4, 2, a.s_post_drop, m.buffers_dict)
+    for i in range(3):
+        y = conv_bn_act(cx, None, y, B, T, "speech_m.postnet.conv_list.%d." % i, "speech_m.postnet.batch_norm_list.%d." % i, 4, 2,
+                        a.s_post_drop, m.buffers_dict)
+    Wp2, b2 = cx.P["speech_m.postnet.conv2.conv.weight"], cx.P["speech_m.postnet.conv2.conv.bias"]
+    post = _empty(B, T, M, like=mel3d)
+    C = y.v.shape[1]
+    ops.gemm(ops.OP_KC_CONV, ops.OP_KC, y.v, C, Wp2, 5 * C, post, M, N, M, 5 * C, conv=(T, C, 0, 4), bias=b2, R=x.v, ldr=M)
+    return post

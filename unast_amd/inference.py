@@ -1,0 +1,186 @@
+"""Autoregressive inference with a per-layer K/V cache.
+
+The reference's infer_sequence (src/network.py:219-252 speech, 455-481 text) re-runs the whole decoder over the growing
+prefix at every step (O(T^2) layer evaluations, `torch.cat` growth, one host sync per step for the stop test).  Here each
+step pushes ONE new position through the decoder: the self-attention keys/values of earlier positions stay in an HBM
+cache, the cross-attention K/V of the memory are projected once per layer, and the stop test is read back every
+`SYNC_EVERY` steps (tokens generated after the true exit step are discarded, so results are identical).
+Positions generated after a sequence has stopped are masked as padded keys exactly as the reference's `dec_mask` does:
+they form a suffix, so the mask is a per-sequence valid length min(i+1, stop_len+1).
+
+Semantics note: with dropout active (model.train() under no_grad, as in cm_text_in / cm_speech_in) the reference draws
+fresh masks for every prefix position at every step; the cached form draws them once per position.  With the RNG sites
+off (parity tests) and in eval mode the two are identical.
+"""
+import math
+
+import torch
+
+from . import ops
+from .utils import SOS_IDX, EOS_IDX, PAD_IDX
+
+SYNC_EVERY = 8
+
+
+def _empty(*shape, dev):
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+
+class _LayerStep:
+    """One decoder layer applied to a single new position per sequence, with cached self-attention K/V."""
+
+    def __init__(self, cx, lp, mem2d, lens_mem, B, Tk, Tcap, H, drop):
+        self.cx, self.lp, self.B, self.Tk, self.Tcap, self.H = cx, lp, B, Tk, Tcap, H
+        self.p = cx.p(drop)
+        self.lens_mem = lens_mem
+        P = cx.P
+        E = mem2d.shape[1]
+        self.E = E
+        Wc, bc = P[lp + "multihead_attn.in_proj_weight"], P[lp + "multihead_attn.in_proj_bias"]
+        self.memkv = _empty(B * Tk, 2 * E, dev=mem2d.device)
+        ops.linear_fwd(mem2d, Wc[E:], bc[E:], self.memkv)                      # projected once for all steps
+        self.cache = torch.zeros(B, Tcap, 2 * E, dtype=torch.float32, device=mem2d.device)
+
+    def _ln(self, z, pre):
+        P = self.cx.P
+        y = torch.empty_like(z)
+        mean = _empty(z.shape[0], dev=z.device)
+        rstd = _empty(z.shape[0], dev=z.device)
+        ops.layernorm_fwd(z, P[pre + "weight"], P[pre + "bias"], y, mean, rstd)
+        return y
+
+    def __call__(self, x, pos, lens_self):
+        cx, lp, B, E, H = self.cx, self.lp, self.B, self.E, self.H
+        P, p, dev = cx.P, self.p, x.device
+        # --- self-attention over the cache (positions 0..pos; stopped sequences keep their frozen valid length)
+        qkv = _empty(B, 3 * E, dev=dev)
+        ops.linear_fwd(x, P[lp + "self_attn.in_proj_weight"], P[lp + "self_attn.in_proj_bias"], qkv)
+        self.cache[:, pos].copy_(qkv[:, E:])                                    # device-memory plumbing: append K|V
+        kv2d = self.cache.view(B * self.Tcap, 2 * E)
+        O = _empty(B, E, dev=dev)
+        lse = _empty(B, H, 1, dev=dev)
+        ops.attn_fwd(qkv[:, :E], kv2d[:, :E], kv2d[:, E:], O, lse, lens_self, B, H, 1, self.Tcap, False, drop_p=p, seed=cx.seed, stream_id=cx.stream())
+        z = _empty(B, E, dev=dev)
+        ops.linear_fwd(O, P[lp + "self_attn.out_proj.weight"], P[lp + "self_attn.out_proj.bias"], z, drop_p=p, seed=cx.seed, stream_id=cx.stream(), R=x)
+        x1 = self._ln(z, lp + "norm1.")
+        # --- cross-attention over the memory
+        Wc, bc = P[lp + "multihead_attn.in_proj_weight"], P[lp + "multihead_attn.in_proj_bias"]
+        q = _empty(B, E, dev=dev)
+        ops.linear_fwd(x1, Wc[:E], bc[:E], q)
+        ops.attn_fwd(q, self.memkv[:, :E], self.memkv[:, E:], O, lse, self.lens_mem, B, H, 1, self.Tk, False, drop_p=p, seed=cx.seed, stream_id=cx.stream())
+        z2 = _empty(B, E, dev=dev)
+        ops.linear_fwd(O, P[lp + "multihead_attn.out_proj.weight"], P[lp + "multihead_attn.out_proj.bias"], z2, drop_p=p, seed=cx.seed, stream_id=cx.stream(), R=x1)
+        x2 = self._ln(z2, lp + "norm2.")
+        # --- feed-forward
+        W1 = P[lp + "linear1.weight"]
+        h = _empty(B, W1.shape[0], dev=dev)
+        ops.linear_fwd(x2, W1, P[lp + "linear1.bias"], h, act=1, drop_p=p, seed=cx.seed, stream_id=cx.stream())
+        z3 = _empty(B, E, dev=dev)
+        ops.linear_fwd(h, P[lp + "linear2.weight"], P[lp + "linear2.bias"], z3, drop_p=p, seed=cx.seed, stream_id=cx.stream(), R=x2)
+        return self._ln(z3, lp + "norm3.")
+
+
+def _posenc_step(cx, x, pe, pos):
+    """PositionalEncoding for one position: x*sqrt(d) + pe[pos], dropout 0.1 (src/module.py:265-267)."""
+    y = torch.empty_like(x)
+    ops.posenc_fwd(x, pe[pos:pos + 1], y, 1, math.sqrt(x.shape[1]), drop_p=cx.p(0.1), seed=cx.seed, stream_id=cx.stream())
+    return y
+
+
+def _exit_step(stop_lens, max_len):
+    """Iteration count at which the reference's loop exits: the step at which the last sequence stopped, else max_len."""
+    sl = stop_lens.tolist()
+    return max(sl) if all(s != max_len for s in sl) else max_len
+
+
+@torch.no_grad()
+def infer_text(m, cx, memory, lens_mem, max_len):
+    """TextTransformer.infer_sequence (src/network.py:455-481)."""
+    B, Tk, E = memory.shape
+    dev = memory.device
+    a = m.args
+    P = cx.P
+    mem2d = memory.contiguous().view(B * Tk, E)
+    layers = [_LayerStep(cx, "text_m.decoder.transformer_decoder.layers.%d." % l, mem2d, lens_mem, B, Tk, max_len, a.nhead, a.d_drop)
+              for l in range(a.num_layers)]
+    tokens = torch.full((B, max_len + 1), PAD_IDX, dtype=torch.int64, device=dev)
+    tokens[:, 0] = SOS_IDX
+    stop_lens = torch.full((B,), max_len, dtype=torch.int64, device=dev)
+    Emb = P["text_m.prenet.embed.weight"]
+    V = P["text_m.postnet.fc1.weight"].shape[0]
+    ldl = (V + 3) // 4 * 4
+    steps = 0
+    for i in range(max_len):
+        cur = tokens[:, i].contiguous()
+        x = _empty(B, E, dev=dev)
+        ops.embed_fwd(cur, Emb, x, 1, drop_p=cx.p(a.t_pre_drop), seed=cx.seed, stream_id=cx.stream())
+        x = _posenc_step(cx, x, m.pe, i)
+        lens_self = torch.clamp(stop_lens + 1, max=i + 1).to(torch.int32)        # dec_mask as a valid-prefix length
+        for L in layers:
+            x = L(x, i, lens_self)
+        pt = cx.p(a.t_post_drop)
+        if pt > 0:
+            xd = torch.empty_like(x)
+            ops.leaky_dropout(x, None, xd, 1.0, drop_p=pt, seed=cx.seed, stream_id=cx.stream())
+            x = xd
+        logits = torch.zeros(B, ldl, dtype=torch.float32, device=dev)
+        ops.linear_fwd(x, P["text_m.postnet.fc1.weight"], P["text_m.postnet.fc1.bias"], logits[:, :V])
+        choice = torch.empty(B, dtype=torch.int64, device=dev)
+        ops.argmax_rows(logits, V, choice)
+        tokens[:, i + 1] = choice
+        newly = (choice == EOS_IDX) & (stop_lens == max_len)                      # loop control on B integers
+        stop_lens = torch.where(newly, torch.full_like(stop_lens, i + 1), stop_lens)
+        steps = i + 1
+        if steps % SYNC_EVERY == 0 and not bool((stop_lens == max_len).any()):
+            break
+    T = min(_exit_step(stop_lens, max_len), steps)
+    res = tokens[:, 1:T + 1].contiguous()
+    keep = torch.arange(T, device=dev)[None, :] < stop_lens[:, None]
+    res = res * keep
+    return res, stop_lens
+
+
+@torch.no_grad()
+def infer_speech(m, cx, memory, lens_mem, max_len, speech_prenet_step, postnet_fn):
+    """SpeechTransformer.infer_sequence (src/network.py:219-252)."""
+    B, Tk, E = memory.shape
+    dev = memory.device
+    a = m.args
+    M = a.num_mels
+    mem2d = memory.contiguous().view(B * Tk, E)
+    layers = [_LayerStep(cx, "speech_m.decoder.transformer_decoder.layers.%d." % l, mem2d, lens_mem, B, Tk, max_len, a.nhead, a.d_drop)
+              for l in range(a.num_layers)]
+    st = cx.st
+    Wh = st.span("speech_m.postnet.linear_project.weight", "speech_m.postnet.stop_linear.weight", (M + 1, E))
+    bh = st.span("speech_m.postnet.linear_project.bias", "speech_m.postnet.stop_linear.bias", (M + 1,))
+    ldh = (M + 1 + 3) // 4 * 4
+    outputs = torch.zeros(B, max_len + 1, M, dtype=torch.float32, device=dev)     # position 0 = all-zero "go" frame
+    stops = torch.zeros(B, max_len + 1, dtype=torch.float32, device=dev)
+    stop_lens = torch.full((B,), max_len, dtype=torch.int64, device=dev)
+    steps = 0
+    for i in range(max_len):
+        frame = outputs[:, i].contiguous()
+        x = speech_prenet_step(cx, frame)
+        x = _posenc_step(cx, x, m.pe, i)
+        lens_self = torch.clamp(stop_lens + 1, max=i + 1).to(torch.int32)
+        for L in layers:
+            x = L(x, i, lens_self)
+        head = torch.zeros(B, ldh, dtype=torch.float32, device=dev)
+        ops.linear_fwd(x, Wh, bh, head[:, :M + 1])
+        outputs[:, i + 1].copy_(head[:, :M])
+        stops[:, i + 1].copy_(head[:, M])
+        stop_mask = (torch.sigmoid(head[:, M]) >= .5) & (stop_lens == max_len)   # loop control (src/network.py:242)
+        stop_lens = torch.where(stop_mask, torch.full_like(stop_lens, i + 1), stop_lens)
+        steps = i + 1
+        if steps % SYNC_EVERY == 0 and not bool((stop_lens == max_len).any()):
+            break
+    T = min(_exit_step(stop_lens, max_len), steps)
+    outs = outputs[:, :T + 1].contiguous()
+    post = postnet_fn(cx, outs)                                                  # outputs + postnet(outputs), [B,T+1,M]
+    pre_res = outs[:, 1:].contiguous()
+    res = post[:, 1:].contiguous()
+    res_stop = stops[:, 1:T + 1].contiguous().unsqueeze(-1)
+    ops.mask_by_len(pre_res, stop_lens)
+    ops.mask_by_len(res, stop_lens)
+    ops.mask_by_len(res_stop, stop_lens)
+    return pre_res, res, res_stop.squeeze(-1), stop_lens

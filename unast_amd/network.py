@@ -171,7 +171,9 @@ class TextTransformer(AutoEncoderNet):
         return dec_out
 
     def infer_sequence(self, memory, masks, max_len=300):
-        raise NotImplementedError("autoregressive inference (cross-model step) is a 'next' row: SURVEY.md section 8f-2")
+        """src/network.py:455-481 with a K/V cache (unast_amd.inference).  Returns (tokens [B,T], stop_lens [B])."""
+        from .inference import infer_text
+        return infer_text(self, self._ctx(), memory.detach(), masks[1], max_len)
 
 
 class SpeechTransformer(AutoEncoderNet):
@@ -249,7 +251,10 @@ class SpeechTransformer(AutoEncoderNet):
         return pre_pred, post_pred, stop_pred
 
     def infer_sequence(self, memory, masks, max_len=815):
-        raise NotImplementedError("autoregressive inference (cross-model step) is a 'next' row: SURVEY.md section 8f-2")
+        """src/network.py:219-252 with a K/V cache.  Returns (pre [B,T,M], post [B,T,M], stop [B,T], stop_lens [B])."""
+        from .inference import infer_speech
+        return infer_speech(self, self._ctx(), memory.detach(), masks[1], max_len,
+                            lambda cx, fr: F.speech_prenet_step(cx, self, fr), lambda cx, mel: F.speech_postnet_residual(cx, self, mel))
 
 
 class LSTMDiscriminator(_Side):
@@ -389,27 +394,45 @@ class UNAST(_Side):
 
     def tts(self, text, text_len, mel, mel_len, infer=False, ret_enc_hid=False):
         t_e_o, t_masks = self.text_m.encode(text, text_len)
-        if infer:
-            raise NotImplementedError("tts(infer=True) needs infer_sequence: SURVEY.md section 8f-2")
-        pre_pred, post_pred, stop_pred, stop_lens = self.speech_m.decode_sequence(mel, mel_len, t_e_o, t_masks, teacher_ratio=1)
+        if not infer:
+            pre_pred, post_pred, stop_pred, stop_lens = self.speech_m.decode_sequence(mel, mel_len, t_e_o, t_masks, teacher_ratio=1)
+        else:
+            pre_pred, post_pred, stop_pred, stop_lens = self.speech_m.infer_sequence(t_e_o, t_masks)
         if ret_enc_hid:
             return pre_pred, post_pred, stop_pred, stop_lens, t_e_o
         return pre_pred, post_pred, stop_pred, stop_lens
 
     def asr(self, text, text_len, mel, mel_len, infer=False, ret_enc_hid=False):
         s_e_o, s_masks = self.speech_m.encode(mel, mel_len)
-        if infer:
-            raise NotImplementedError("asr(infer=True) needs infer_sequence: SURVEY.md section 8f-2")
-        text_pred = self.text_m.decode_sequence(text, text_len, s_e_o, s_masks, teacher_ratio=1)
+        if not infer:
+            text_pred = self.text_m.decode_sequence(text, text_len, s_e_o, s_masks, teacher_ratio=1)
+        else:
+            text_pred = self.text_m.infer_sequence(s_e_o, s_masks)
         if ret_enc_hid:
             return text_pred, s_e_o
         return text_pred
 
     def cm_text_in(self, text, text_len, ret_enc_hid=False):
-        raise NotImplementedError("cross-model (back-translation) step is a 'next' row: SURVEY.md section 8f-2")
+        """src/network.py:103-112: text -> (no grad) TTS inference -> speech encoder -> text decoder."""
+        with torch.no_grad():
+            t_e_o, t_mask = self.text_m.encode(text, text_len)
+            _, post_pred, _, pred_lens = self.speech_m.infer_sequence(t_e_o, t_mask)
+        cm_s_e_o, cm_mask = self.speech_m.encode(post_pred.detach(), pred_lens.detach())
+        text_pred = self.text_m.decode_sequence(text, text_len, cm_s_e_o, cm_mask, teacher_ratio=1)
+        if ret_enc_hid:
+            return text_pred, cm_s_e_o, pred_lens
+        return text_pred
 
     def cm_speech_in(self, mel, mel_len, ret_enc_hid=False):
-        raise NotImplementedError("cross-model (back-translation) step is a 'next' row: SURVEY.md section 8f-2")
+        """src/network.py:114-123: speech -> (no grad) ASR inference -> text encoder -> speech decoder."""
+        with torch.no_grad():
+            s_e_o, s_mask = self.speech_m.encode(mel, mel_len)
+            text_pred, text_pred_len = self.text_m.infer_sequence(s_e_o, s_mask)
+        cm_t_e_o, cm_t_masks = self.text_m.encode(text_pred.detach(), text_pred_len.detach())
+        pre_pred, post_pred, stop_pred, stop_lens = self.speech_m.decode_sequence(mel, mel_len, cm_t_e_o, cm_t_masks, teacher_ratio=1)
+        if ret_enc_hid:
+            return pre_pred, post_pred, stop_pred, cm_t_e_o, text_pred_len
+        return pre_pred, post_pred, stop_pred
 
     def num_params(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)

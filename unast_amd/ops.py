@@ -196,6 +196,16 @@ def add_inplace(a, b):
     check(lib().unast_add_inplace(_p(a), _p(b), a.numel(), _stream()), "unast_add_inplace")
 
 
+def argmax_rows(x2d, cols, out_i64):
+    check(lib().unast_argmax_rows(_p(x2d), x2d.stride(0), x2d.shape[0], cols, _p(out_i64), _stream()), "unast_argmax_rows")
+
+
+def mask_by_len(x3d, lens_i64):
+    B, T = x3d.shape[0], x3d.shape[1]
+    D = x3d.numel() // (B * T)
+    check(lib().unast_mask_by_len(_p(x3d), _p(lens_i64), B, T, D, _stream()), "unast_mask_by_len")
+
+
 def scale_inplace(a, alpha):
     check(lib().unast_scale_inplace(_p(a), float(alpha), a.numel(), _stream()), "unast_scale_inplace")
 

@@ -13,7 +13,8 @@ Differences that are deliberate and MI355X-motivated:
     `losses` dict receives 0-dim device tensors unless `SYNC_LOSSES` is True (the reference syncs 6+ times per sub-step);
   * `optimizer_step` with the FusedAdamW built by `initialize_model` = global-norm + clip + AdamW in two launches over
     the flat buffers, preceded by ONE all-reduce of the active gradient range when torch.distributed is initialised;
-  * cm_steps (autoregressive back-translation) is not on this path yet.
+  * cm_steps (back-translation) generates with a K/V-cached decoder (unast_amd/inference.py) instead of re-running the
+    decoder over the growing prefix at every step.
 """
 import math
 import os
@@ -234,7 +235,26 @@ def supervised_step(model, batch, args, use_dis_loss=False):
 
 
 def crossmodel_step(model, batch, args, use_dis_loss=False):
-    raise NotImplementedError("cross-model (back-translation) step: SURVEY.md section 8f-2 ('next' row)")
+    """src/train.py:261-294."""
+    x, y = batch
+    text, mel, text_len, mel_len = x
+    gold_char, gold_mel, gold_stop = y
+    if use_dis_loss:
+        pre_pred, post_pred, stop_pred, cm_t_hid, cm_t_len = model.cm_speech_in(mel, mel_len, ret_enc_hid=use_dis_loss)
+    else:
+        pre_pred, post_pred, stop_pred = model.cm_speech_in(mel, mel_len)
+    s_cm_loss = speech_loss(gold_mel, gold_stop, pre_pred, post_pred, mel_len, stop_pred, args.s_eos_weight)
+    if use_dis_loss:
+        text_pred, cm_s_hid, cm_s_len = model.cm_text_in(text, text_len, ret_enc_hid=use_dis_loss)
+        text_pred = text_pred.permute(0, 2, 1)
+    else:
+        text_pred = model.cm_text_in(text, text_len).permute(0, 2, 1)
+    t_cm_loss = text_loss(gold_char, text_pred, args.t_eos_weight)
+    if use_dis_loss:
+        d_batch = discriminator_shuffle_batch(cm_t_hid, cm_t_len, cm_s_hid, cm_s_len, args.model_type)
+        d_cm_loss, _ = discriminator_hidden_to_loss(model, d_batch, freeze_discriminator=True)
+        return t_cm_loss, s_cm_loss, d_cm_loss
+    return t_cm_loss, s_cm_loss
 
 
 def discriminator_shuffle_batch(t_hid, t_hid_len, s_hid, s_hid_len, model_type, train_discriminator=False):
@@ -347,7 +367,21 @@ def train_ae_step(losses, model, batch, step, accum_steps, args):
 
 
 def train_cm_step(losses, model, batch, step, accum_steps, args):
-    raise NotImplementedError("cross-model (back-translation) step: SURVEY.md section 8f-2 ('next' row)")
+    """src/train.py:418-444."""
+    batch = process_batch(batch)
+    if args.use_discriminator:
+        t_cm_loss, s_cm_loss, d_cm_loss = crossmodel_step(model, batch, args, args.use_discriminator)
+        loss = s_cm_loss + t_cm_loss + d_cm_loss
+    else:
+        t_cm_loss, s_cm_loss = crossmodel_step(model, batch, args)
+        loss = s_cm_loss + t_cm_loss
+    loss = loss / accum_steps
+    loss.backward()
+    losses['s_cm'].append(_log(s_cm_loss))
+    losses['t_cm'].append(_log(t_cm_loss))
+    if args.use_discriminator:
+        losses['d_cm'].append(_log(d_cm_loss))
+    return loss
 
 
 def train_discriminator_step(losses, model, batch, step, accum_steps, args, log_out_to_tb=False):
@@ -373,17 +407,17 @@ def unfreeze_model_parameters(model):
 
 
 def train_step(losses, model, optimizer, scheduler, batches, step, args):
-    """One iteration of the hot loop of train() (src/train.py:602-655) with cm_steps = 0.
-    `batches` = dict(unsup=[...ae_steps batches], sup=[...sp_steps], disc=[...d_steps])."""
+    """One iteration of the hot loop of train() (src/train.py:602-655).
+    `batches` = dict(unsup=[...ae_steps batches], cm=[...cm_steps], sup=[...sp_steps], disc=[...d_steps])."""
     if not model.training:
         model.train()
     if args.use_discriminator:
         freeze_model_parameters(model.discriminator)
     accum_steps = args.ae_steps + getattr(args, "cm_steps", 0) + args.sp_steps
-    if getattr(args, "cm_steps", 0):
-        raise NotImplementedError("cm_steps > 0: SURVEY.md section 8f-2")
     for si in range(args.ae_steps):
         train_ae_step(losses, model, batches["unsup"][si], step, accum_steps, args)
+    for si in range(getattr(args, "cm_steps", 0)):
+        train_cm_step(losses, model, batches["cm"][si], step, accum_steps, args)
     for si in range(args.sp_steps):
         train_sp_step(losses, model, batches["sup"][si], step, accum_steps, args)
     optimizer_step(model, optimizer, args)
@@ -425,12 +459,11 @@ def train(args, batch_getter=None, on_epoch_end=None):
     per outer step ae_steps x AE, sp_steps x SP (accumulated, scaled by 1/accum_steps), optimizer_step, then d_steps x D,
     optimizer_step, scheduler.step().  Returns (model, per-epoch loss means)."""
     set_seed(args.seed)
-    if getattr(args, "cm_steps", 0):
-        raise NotImplementedError("cm_steps > 0 (cross-model back-translation): SURVEY.md section 8f-2")
     batch_getter = batch_getter or SyntheticBatchGetter(args)
     s_epoch, best, model, optimizer, scheduler = initialize_model(args)
-    max_obj_steps = max(args.ae_steps, args.sp_steps, args.d_steps if args.use_discriminator else 0)
-    accum_steps = args.ae_steps + args.sp_steps
+    cm_steps = getattr(args, "cm_steps", 0)
+    max_obj_steps = max(args.ae_steps, cm_steps, args.sp_steps, args.d_steps if args.use_discriminator else 0)
+    accum_steps = args.ae_steps + cm_steps + args.sp_steps
     history = []
     for epoch in range(s_epoch, args.epochs):
         losses = defaultdict(list)
@@ -441,6 +474,9 @@ def train(args, batch_getter=None, on_epoch_end=None):
             for si in range(args.ae_steps):
                 step = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps + si
                 train_ae_step(losses, model, batch_getter.get_unsupervised_batch(), step, accum_steps, args)
+            for si in range(cm_steps):
+                step = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps + si
+                train_cm_step(losses, model, batch_getter.get_unsupervised_batch(), step, accum_steps, args)
             for si in range(args.sp_steps):
                 step = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps + si
                 train_sp_step(losses, model, batch_getter.get_supervised_batch(), step, accum_steps, args)
