@@ -87,6 +87,11 @@ int unast_bn_fwd(const float* x, const float* gamma, const float* beta, float* y
                  float* running_mean, float* running_var, double* ws, int rows, int C,
                  float eps, float momentum, int act, float drop_p, unsigned int seed, unsigned int stream_id,
                  hipStream_t stream);
+/* Eval-mode BatchNorm1d + activation (model.eval(): running statistics, no dropout), as evaluate() runs it
+ * (src/train.py:484; src/module.py:162-165, 223-230).  mean/rstd: C floats of scratch. */
+int unast_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float* y, float* mean, float* rstd, int rows, int C, float eps, int act,
+                      hipStream_t stream);
 int unast_bn_bwd(float* dy_inout, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                  float* dx, float* dgamma, float* dbeta, double* ws, int rows, int C, int act,
                  float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);

@@ -154,3 +154,38 @@ def test_golden_fixtures_are_data_only(golden_dir):
         z = np.load(os.path.join(golden_dir, f), allow_pickle=False)
         for k in z.files:
             assert z[k].dtype.kind in "fiubU", (f, k, z[k].dtype)
+
+
+def test_edit_distance_and_per_known_answers():
+    """compute_per restates jiwer==2.2.0's wer (requirements.txt:10; absent here): flatten, Levenshtein / len(truth)."""
+    import random
+    from unast_amd.utils import edit_distance, compute_per
+    assert edit_distance([], []) == 0 and edit_distance([1, 2], []) == 2 and edit_distance([], [5]) == 1
+    k, s = [ord(c) for c in "kitten"], [ord(c) for c in "sitting"]
+    assert edit_distance(k, s) == 3 and edit_distance(s, k) == 3
+    assert edit_distance([1, 2, 3, 4], [1, 2, 3, 4]) == 0
+    assert edit_distance([1, 2, 3, 4], [2, 3, 4]) == 1 and edit_distance([1, 2, 3], [4, 1, 2, 3, 5]) == 2
+
+    def slow(a, b):                                         # textbook O(nm) table
+        d = [[max(i, j) if 0 in (i, j) else 0 for j in range(len(b) + 1)] for i in range(len(a) + 1)]
+        for i in range(1, len(a) + 1):
+            for j in range(1, len(b) + 1):
+                d[i][j] = min(d[i - 1][j] + 1, d[i][j - 1] + 1, d[i - 1][j - 1] + (a[i - 1] != b[j - 1]))
+        return d[-1][-1]
+    rnd = random.Random(0)
+    for _ in range(50):
+        a = [rnd.randrange(4) for _ in range(rnd.randrange(0, 30))]
+        b = [rnd.randrange(4) for _ in range(rnd.randrange(0, 30))]
+        assert edit_distance(a, b) == slow(a, b)
+    gt = torch.tensor([[5, 6, 7, 2, 0], [8, 9, 2, 0, 0]])
+    hyp = torch.tensor([[5, 7, 2, 0, 0, 0], [8, 9, 9, 2, 0, 0]])
+    per = compute_per(gt, hyp, torch.tensor([4, 3]), torch.tensor([3, 4]))
+    assert per == pytest.approx(2 / 7)                      # one deletion + one insertion over 7 reference symbols
+    assert compute_per(gt, gt, torch.tensor([4, 3]), torch.tensor([4, 3])) == 0.0
+
+
+def test_compute_d_score():
+    from unast_amd.train import compute_d_score
+    out = torch.tensor([2.0, -1.0, 0.3, -0.2])
+    tgt = torch.tensor([0.9, 0.1, 0.1, 0.9])
+    assert int(compute_d_score(out, tgt)) == 2

@@ -415,6 +415,26 @@ extern "C" int unast_bn_fwd(const float* x, const float* gamma, const float* bet
     return unast_check_launch("unast_bn_fwd");
 }
 
+// Eval-mode statistics: mean = running_mean, rstd = 1/sqrt(running_var + eps).
+__global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var, int C, float eps,
+                                     float* __restrict__ mean, float* __restrict__ rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = running_mean[c];
+    rstd[c] = 1.f / sqrtf(running_var[c] + eps);
+}
+
+extern "C" int unast_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float* y, float* mean, float* rstd, int rows, int C, float eps, int act,
+                                 hipStream_t stream) {
+    UNAST_REQUIRE(x && gamma && beta && running_mean && running_var && y && mean && rstd, "unast_bn_eval_fwd: null pointer");
+    UNAST_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "unast_bn_eval_fwd: need rows>0, C%%4==0 (rows=%d C=%d)", rows, C);
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, running_mean, running_var, C, eps, mean, rstd);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for((size_t)rows * (C / 4), 256)), dim3(256), 0, stream, x, mean, rstd, gamma, beta, y,
+                       rows, C, act, 0u, 1.f, 0u, 0u);
+    return unast_check_launch("unast_bn_eval_fwd");
+}
+
 extern "C" int unast_bn_bwd(float* dy_inout, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                             float* dx, float* dgamma, float* dbeta, double* ws /* 2*C doubles */, int rows, int C, int act,
                             float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream) {

@@ -23,7 +23,8 @@ class Ctx:
         self.st = store
         self.P = store.phys
         self.training = training
-        self.stochastic = training and not is_deterministic()      # dropout / noise sites active
+        self.stochastic = training and not is_deterministic()      # dropout sites active
+        self.noisy = not is_deterministic()                         # noise_fn ignores model.training (src/utils.py:40-49)
         self.seed = seed & 0xFFFFFFFF
         self._stream = 0
 
@@ -230,11 +231,15 @@ def conv_bn_act(cx, tape, x, B, T, conv_pre, bn_pre, pad_left, act, drop, bn_buf
     y = _empty(N, Cout, like=x.v)
     mean, rstd = _empty(Cout, like=x.v), _empty(Cout, like=x.v)
     ws = torch.empty(2 * Cout, dtype=torch.float64, device=x.v.device)
-    rm, rv = (bn_buffers[bn_pre + "running_mean"], bn_buffers[bn_pre + "running_var"]) if cx.training else (None, None)
+    rm, rv = bn_buffers[bn_pre + "running_mean"], bn_buffers[bn_pre + "running_var"]
     gamma, beta = cx.P[bn_pre + "weight"], cx.P[bn_pre + "bias"]
-    ops.bn_fwd(c.view(N, Cout), gamma, beta, y, mean, rstd, rm, rv, ws, act, drop_p=p, seed=cx.seed, stream_id=s)
     if cx.training:
+        ops.bn_fwd(c.view(N, Cout), gamma, beta, y, mean, rstd, rm, rv, ws, act, drop_p=p, seed=cx.seed, stream_id=s)
         bn_buffers[bn_pre + "num_batches_tracked"] += 1
+    else:
+        if tape is not None:
+            raise NotImplementedError("eval-mode BatchNorm has no backward on this path; evaluate() runs under torch.no_grad()")
+        ops.bn_eval_fwd(c.view(N, Cout), gamma, beta, rm, rv, y, mean, rstd, act)
     out = Var(y)
     if tape is not None:
         seed = cx.seed
@@ -263,7 +268,7 @@ def text_embed(cx, tape, ids, T, drop, noise, shift_sos):
     E = cx.P["text_m.prenet.embed.weight"]
     N = ids.numel()
     p = cx.p(drop)
-    pn = 0.3 if (noise and cx.stochastic) else 0.0
+    pn = 0.3 if (noise and cx.noisy) else 0.0
     s, sn = cx.stream(), cx.stream()
     y = _empty(N, E.shape[1], device=E.device)
     ops.embed_fwd(ids, E, y, T, shift_sos=shift_sos, drop_p=p, seed=cx.seed, stream_id=s, noise_p=pn, noise_stream=sn)
@@ -373,7 +378,7 @@ def speech_encode(cx, tape, m, mel, lens, noise):
     B, T, M = mel.shape
     a = m.args
     mel2d = mel.reshape(B * T, M)
-    if noise and cx.stochastic:
+    if noise and cx.noisy:
         noised = _empty(B * T, M, like=mel2d)
         ops.rowmask(mel2d, noised, 0.3, cx.seed, cx.stream())
         mel2d = noised

@@ -158,6 +158,12 @@ def bn_fwd(x2d, gamma, beta, y, mean, rstd, running_mean, running_var, ws, act, 
                              eps, momentum, act, drop_p, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_bn_fwd")
 
 
+def bn_eval_fwd(x2d, gamma, beta, running_mean, running_var, y, mean, rstd, act, eps=1e-5):
+    rows, C = x2d.shape
+    check(lib().unast_bn_eval_fwd(_p(x2d), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(rstd), rows, C,
+                                  eps, act, _stream()), "unast_bn_eval_fwd")
+
+
 def bn_bwd(dy_inout, x2d, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, act, drop_p=0.0, seed=0, stream_id=0):
     rows, C = x2d.shape
     check(lib().unast_bn_bwd(_p(dy_inout), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta), _p(ws), rows, C,

@@ -454,8 +454,9 @@ def log_loss_metrics(losses, epoch, eval=False):
     return out
 
 
-def train(args, batch_getter=None, on_epoch_end=None):
-    """The hot loop of the reference's train() (src/train.py:567-696) without evaluation / TensorBoard / dataset code:
+def train(args, batch_getter=None, on_epoch_end=None, valid_dataloader=None):
+    """The hot loop of the reference's train() (src/train.py:567-696) without TensorBoard / dataset code (evaluation and
+    best-PER checkpointing run at each epoch end when `valid_dataloader` is given, src/train.py:668-679):
     per outer step ae_steps x AE, sp_steps x SP (accumulated, scaled by 1/accum_steps), optimizer_step, then d_steps x D,
     optimizer_step, scheduler.step().  Returns (model, per-epoch loss means)."""
     set_seed(args.seed)
@@ -495,10 +496,96 @@ def train(args, batch_getter=None, on_epoch_end=None):
         if getattr(args, "checkpoint_path", None):
             from .checkpoint import save_ckp
             save_ckp(epoch, 300.0, model, optimizer, False, args.checkpoint_path)
+        if valid_dataloader is not None:
+            step = (epoch + 1) * args.epoch_steps * max_obj_steps - 1
+            per, eval_losses = evaluate(model, valid_dataloader, step, args)
+            history[-1].update({"eval/" + k: v for k, v in log_loss_metrics(eval_losses, epoch, eval=True).items()})
+            history[-1]["eval/per"] = per
+            if getattr(args, "checkpoint_path", None):
+                save_ckp(epoch, per, model, optimizer, per < best, args.checkpoint_path)
+            print("Eval_ epoch {:-3d} PER {:0.3f}%".format(epoch, per * 100))
+            best = min(best, per)
         if on_epoch_end is not None:
             on_epoch_end(epoch, model, optimizer, history[-1])
     model.eval()
     return model, history
+
+
+####---- Evaluation (src/train.py:474-565, 978-983) ----####
+def compute_d_score(outputs, targets):
+    """src/train.py:978-983: number of discriminator outputs on the right side of 0.5."""
+    return torch.sum(torch.round(torch.sigmoid(outputs)) == torch.round(targets))
+
+
+def evaluate(model, valid_dataloader, step, args, is_test=False):
+    """src/train.py:474-565.  Expects paired speech & text batches.  Returns (per, losses[, d_score]).
+    model.eval(): BatchNorm uses running statistics, dropout is off; noise_fn / specaugment stay active as in the
+    reference (they do not look at model.training)."""
+    import json
+    import numpy as np
+    from .utils import compute_per, compare_outputs
+    if is_test:
+        os.makedirs(os.path.join(args.out_test_dir, 'mels'), exist_ok=True)
+    model.eval()
+    with torch.no_grad():
+        losses = defaultdict(list)
+        per, n_iters, d_score = 0, 0, 0
+        text_pred_dict = {}
+        text = None
+        for batch in valid_dataloader:
+            if is_test:
+                batch, fnames = batch
+            batch = process_batch(batch)
+            x, _ = batch
+            text, mel, text_len, mel_len = x
+            out = autoencoder_step(model, batch, args, args.use_discriminator)
+            losses['t_ae'].append(out[0].item())
+            losses['s_ae'].append(out[1].item())
+            if args.use_discriminator:
+                losses['d_ae'].append(out[2].item())
+            out = supervised_step(model, batch, args, args.use_discriminator)
+            losses['asr'].append(out[0].item())
+            losses['tts'].append(out[1].item())
+            if args.use_discriminator:
+                losses['d_sp'].append(out[2].item())
+            out = crossmodel_step(model, batch, args, args.use_discriminator)
+            losses['s_cm'].append(out[1].item())
+            losses['t_cm'].append(out[0].item())
+            if args.use_discriminator:
+                losses['d_cm'].append(out[2].item())
+            if args.use_discriminator:
+                d_loss, d_output = discriminator_step(model, batch, args)
+                losses['dis'].append(d_loss.item())
+                if is_test:
+                    d_score += compute_d_score(d_output[0], d_output[1]).item() / args.eval_batch_size / 2
+            text_pred, text_pred_len = model.asr(None, None, mel, mel_len, infer=True)
+            per += compute_per(text, text_pred, text_len, text_pred_len)
+            n_iters += 1
+            if is_test:
+                tp, tpl = text_pred.cpu(), text_pred_len.cpu()
+                for gt, gt_len, pred, pred_len, fname in zip(text.cpu(), text_len.cpu(), tp, tpl, fnames):
+                    text_pred_dict[fname] = {'gt': gt.tolist()[:gt_len.item()], 'pred': pred.tolist()[:pred_len.item()]}
+                _, post_pred, _, stop_lens = model.tts(text, text_len, None, None, infer=True)
+                for pred, stop_len, fname in zip(post_pred.cpu(), stop_lens.cpu(), fnames):
+                    np.save(os.path.join(args.out_test_dir, 'mels', fname + '.pt'), pred.numpy()[:stop_len.item()])
+        if n_iters == 0:
+            raise ValueError("evaluate: empty dataloader")
+        compare_outputs(text[-1], text_pred[-1], text_len[-1], text_pred_len[-1])
+    if is_test:
+        json.dump(text_pred_dict, open(os.path.join(args.out_test_dir, 'text_preds.json'), 'w'))
+        return per / n_iters, losses, d_score / n_iters
+    return per / n_iters, losses
+
+
+def evaluate_main(args, test_dataloader):
+    """src/train.py:985-999 with the dataloader passed in (the LJSpeech dataset code is outside this path)."""
+    set_seed(args.seed)
+    s_epoch, _, model, _, _ = initialize_model(args)
+    per, eval_losses, d_score = evaluate(model, test_dataloader, s_epoch, args, is_test=True)
+    log_loss_metrics(eval_losses, s_epoch, eval=True)
+    print("per : {}".format(per))
+    print("d_score : {}".format(d_score))
+    return per, eval_losses, d_score
 
 
 #####----- Model, optimizer, scheduler initializations -----#####

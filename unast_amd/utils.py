@@ -104,3 +104,49 @@ class TeacherRatio():
 
 def get_teacher_ratio(args):
     return TeacherRatio(args)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Evaluation helpers (src/utils.py:24-38)
+# ---------------------------------------------------------------------------------------------------------------
+def edit_distance(ref, hyp):
+    """Levenshtein distance between two integer sequences (unit costs).  One DP row per reference symbol; the
+    insertion chain inside a row is resolved with a running minimum, so each row is a handful of numpy vector ops."""
+    ref = np.asarray(ref, dtype=np.int64).ravel()
+    hyp = np.asarray(hyp, dtype=np.int64).ravel()
+    n, m = ref.size, hyp.size
+    if n == 0 or m == 0:
+        return int(max(n, m))
+    ar = np.arange(m + 1, dtype=np.int64)
+    prev = ar.copy()
+    cur = np.empty(m + 1, dtype=np.int64)
+    for i in range(1, n + 1):
+        cur[0] = i
+        np.minimum(prev[1:] + 1, prev[:-1] + (hyp != ref[i - 1]), out=cur[1:])
+        cur[:] = np.minimum.accumulate(cur - ar) + ar              # cur[j] = min(cur[j], cur[j-1] + 1) for all j
+        prev, cur = cur, prev
+    return int(prev[m])
+
+
+def compute_per(ground_truth, hypothesis, ground_truth_lengths, hypothesis_lengths):
+    """Phoneme error rate of a batch (src/utils.py:24-34).  The reference joins each id sequence into a string of
+    "words" and calls jiwer.wer (jiwer==2.2.0, requirements.txt:10 -- not installed in this image).  That version's
+    published algorithm: both sentence lists are flattened into ONE word list each, and
+    wer = (S + D + I) / (H + S + D) = Levenshtein(truth, hypothesis) / len(truth)."""
+    gt, hy = _to_lists(ground_truth), _to_lists(hypothesis)
+    gl, hl = _to_lists(ground_truth_lengths), _to_lists(hypothesis_lengths)
+    ref = [t for b in range(len(gt)) for t in gt[b][:gl[b]]]
+    hyp = [t for b in range(len(gt)) for t in hy[b][:hl[b]]]
+    if not ref:
+        raise ValueError("compute_per: empty ground truth")
+    return edit_distance(ref, hyp) / float(len(ref))
+
+
+def _to_lists(t):
+    return t.detach().cpu().tolist() if torch.is_tensor(t) else np.asarray(t).tolist()
+
+
+def compare_outputs(ground_truth, hypothesis, gt_len, hyp_len):
+    """src/utils.py:36-38; prints ids (the symbol table belongs to the reference's text front end, outside this path)."""
+    print("Model prediction of length %d " % int(hyp_len), _to_lists(hypothesis)[:int(hyp_len)])
+    print("Ground Truth of length %d " % int(gt_len), _to_lists(ground_truth)[:int(gt_len)])
