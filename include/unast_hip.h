@@ -39,8 +39,10 @@ const char* unast_arch(void);
  *           splitk_ws == NULL the partials are added to C with fp32 atomics (needs beta=1).
  * rowsum_a (a_mode 2 only, may be NULL): rowsum_a[m] += sum_k A[m][k] — the bias gradient sum_tokens dY fused into
  *           the weight-gradient pass that already streams dY.
- * tile_wn: block tile width 64*tile_wn columns (2 or 4); 0 lets the library choose (128x256 when N >= 192 and the
- *           grid still fills the chip). */
+ * tile_wn: 2 = 128x128 tile / 4 waves, 8 = 128x128 tile / 8 waves, 4 = 128x256 tile / 8 waves; 0 lets the library
+ *           choose (8 waves for forward / dgrad forms, 4 waves for weight gradients).
+ * b_presplit: B points into a copy of the weights kept in the pre-split operand format written by unast_adamw /
+ *           unast_split_f32 (same byte offsets as the fp32 weights), so the kernel does not re-split them per row panel. */
 int unast_gemm(int a_mode, int b_mode, int nsplit,
                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                int M, int N, int K, int kb_valid,
@@ -48,7 +50,8 @@ int unast_gemm(int a_mode, int b_mode, int nsplit,
                const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale,
                float alpha, int beta, int act,
                float drop_p, unsigned int seed, unsigned int stream_id,
-               int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, int tile_wn, hipStream_t stream);
+               int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, int tile_wn, int b_presplit,
+               hipStream_t stream);
 
 /* Fused multi-head attention core (head_dim 64), flash-style.  Replaces the softmax(QK^T/sqrt(d)+mask) -> dropout -> V
  * core of torch.nn.MultiheadAttention inside torch.nn.TransformerEncoderLayer/DecoderLayer
@@ -163,10 +166,14 @@ int unast_lstm_bwd(const float* dy, const float* dhfinal, const float* whh, cons
 int unast_leaky_dropout(const float* x, const float* dy, float* out, int rows, int D, float slope, float drop_p, unsigned int seed,
                         unsigned int stream_id, hipStream_t stream);
 
-/* optimizer_step (src/train.py:358-363): clip_grad_norm_ + torch.optim.AdamW over flat fp32 buffers. */
+/* optimizer_step (src/train.py:358-363): clip_grad_norm_ + torch.optim.AdamW over flat fp32 buffers.
+ * split_out (may be NULL; needs n % 4 == 0): the updated parameters once more in the GEMM's pre-split operand format --
+ * per 4 consecutive elements one 16-byte chunk [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] of bf16, hi = RNE(x), lo = RNE(x - hi).
+ * unast_split_f32 produces the same format from any fp32 buffer (model load, load_state_dict). */
 int unast_sumsq(const float* g, int64_t n, double* out, hipStream_t stream);
 int unast_adamw(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
-                float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream);
+                float beta1, float beta2, float eps, float weight_decay, int step, float* split_out, hipStream_t stream);
+int unast_split_f32(const float* src, float* dst, int64_t n, hipStream_t stream);
 
 #ifdef __cplusplus
 }

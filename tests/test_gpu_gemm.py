@@ -18,7 +18,7 @@ TOL = {3: 3e-5, 1: 2e-2}
 
 @pytest.mark.parametrize("nsplit", [3, 1])
 @pytest.mark.parametrize("M,N,K", [(200, 256, 256), (333, 81, 256), (128, 1024, 256), (77, 256, 1024), (513, 46, 256),
-                                   (40, 256, 80), (3000, 1024, 256), (2500, 1100, 64)])
+                                   (40, 256, 80), (3000, 1024, 256), (2500, 1100, 64), (1024, 256, 512), (2048, 1024, 256), (256, 128, 96), (96, 256, 256), (32, 256, 128)])
 def test_linear_fwd_dgrad_wgrad(nsplit, M, N, K):
     from unast_amd import ops, config
     config.NSPLIT = nsplit
@@ -44,10 +44,12 @@ def test_linear_fwd_dgrad_wgrad(nsplit, M, N, K):
     ops.linear_dgrad(dy.to(dev())[:, :N], W.to(dev()), dx, G=gate.to(dev()), gate_scale=2.0)
     ref = (dy[:, :N].double() @ W.double()) * (gate > 0).double() * 2.0
     assert relerr(dx, ref) < TOL[nsplit]
-    # wgrad accumulates
+    # wgrad accumulates (and carries the fused bias gradient)
     dW = torch.ones(N, K, device=dev())
-    ops.linear_wgrad(dy.to(dev())[:, :N], x.to(dev()), dW)
+    db = torch.ones(N, device=dev())
+    ops.linear_wgrad(dy.to(dev())[:, :N], x.to(dev()), dW, db=db)
     assert relerr(dW, 1.0 + dy[:, :N].double().t() @ x.double()) < TOL[nsplit]
+    assert relerr(db, 1.0 + dy[:, :N].double().sum(0)) < 1e-5
     config.NSPLIT = 3
 
 
@@ -100,3 +102,93 @@ def test_gemm_rejects_bad_arguments():
     x = torch.ones(8, 6, device=dev()); W = torch.ones(4, 6, device=dev()); y = torch.empty(8, 4, device=dev())
     with pytest.raises(UnastHipError):
         ops.linear_fwd(x, W, None, y)              # lda = 6 is not a multiple of 4
+
+
+@pytest.mark.parametrize("nsplit", [3, 1])
+@pytest.mark.parametrize("M,N,K", [(1024, 256, 512), (384, 768, 256), (200, 81, 256), (130, 256, 80)])
+def test_presplit_weights_are_bit_identical(nsplit, M, N, K):
+    """Weights read from the pre-split copy (written by unast_split_f32 / the AdamW kernel) give the same bits as weights
+    split inside the GEMM, on the interior fast path and on the general path, forward and dgrad; conv forms as well."""
+    from unast_amd import ops, config
+    config.NSPLIT = nsplit
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev())
+    W = (torch.randn(N, K, generator=g) * 0.1).to(dev())
+    Ws = torch.empty_like(W)
+    ops.split_f32(W, Ws)
+    dy = torch.randn(M, N + (-N) % 4, generator=g).to(dev())[:, :N]
+    outs = []
+    for presplit in (False, True):
+        if presplit:
+            ops.register_weight_span(W.data_ptr(), W.numel() * 4, Ws.data_ptr())
+        try:
+            y = torch.empty(M, N + (-N) % 4, device=dev())
+            ops.linear_fwd(x, W, None, y[:, :N])
+            dx = torch.empty(M, K, device=dev())
+            ops.linear_dgrad(dy, W, dx)
+            outs.append((y[:, :N].clone(), dx))
+        finally:
+            ops.unregister_weight_span(W.data_ptr())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert relerr(outs[1][0], x.double().cpu() @ W.double().cpu().t()) < TOL[nsplit]
+    config.NSPLIT = 3
+
+
+def test_presplit_conv_and_adamw_refresh():
+    from unast_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, T, Cin, Cout = 2, 40, 256, 256
+    x = torch.randn(B, T, Cin, generator=g).to(dev())
+    Wp = (torch.randn(Cout, 5, Cin, generator=g) * 0.05).to(dev())
+    dy = torch.randn(B, T, Cout, generator=g).to(dev())
+    ref_y = torch.empty(B, T, Cout, device=dev()); ops.conv_fwd(x, Wp, None, ref_y, 2)
+    ref_dx = torch.empty(B, T, Cin, device=dev()); ops.conv_dgrad(dy, Wp, ref_dx, 2)
+    Ws = torch.empty_like(Wp); ops.split_f32(Wp, Ws)
+    ops.register_weight_span(Wp.data_ptr(), Wp.numel() * 4, Ws.data_ptr())
+    try:
+        y = torch.empty(B, T, Cout, device=dev()); ops.conv_fwd(x, Wp, None, y, 2)
+        dx = torch.empty(B, T, Cin, device=dev()); ops.conv_dgrad(dy, Wp, dx, 2)
+    finally:
+        ops.unregister_weight_span(Wp.data_ptr())
+    assert torch.equal(y, ref_y) and torch.equal(dx, ref_dx)
+    # the AdamW kernel refreshes the split copy of what it updates
+    n = 4096
+    p = torch.randn(n, generator=g).to(dev()); gr = torch.randn(n, generator=g).to(dev())
+    m = torch.zeros(n, device=dev()); v = torch.zeros(n, device=dev()); ss = torch.zeros(1, dtype=torch.float64, device=dev())
+    sp = torch.zeros(n, device=dev())
+    ops.sumsq(gr, ss)
+    ops.adamw(p, gr, m, v, ss, 1.0, 1e-2, 0.9, 0.999, 1e-8, 1e-6, 1, split_out=sp)
+    want = torch.empty(n, device=dev()); ops.split_f32(p, want)
+    assert torch.equal(sp.view(torch.int32), want.view(torch.int32))
+    # format: per 4 values [hi x4 | lo x4] bf16, hi + lo ~ value to ~2^-16
+    chunks = want.view(torch.int16).view(-1, 8).cpu()
+    hi = (chunks[:, :4].to(torch.int32) << 16).view(torch.float32)
+    lo = (chunks[:, 4:].to(torch.int32) << 16).view(torch.float32)
+    assert ((hi + lo).view(-1) - p.cpu()).abs().max() <= p.abs().max().item() * 2 ** -15
+
+
+@pytest.mark.parametrize("nsplit", [3, 1])
+@pytest.mark.parametrize("M,N,K", [(1024, 256, 512), (200, 81, 256), (130, 256, 80), (513, 1024, 256), (96, 384, 64), (256, 128, 32)])
+def test_tile_variants_agree_bitwise(nsplit, M, N, K):
+    """The 8-wave and 4-wave tilings (interior fast path or general path) give the same bits: same products, same k order."""
+    from unast_amd import ops, config
+    config.NSPLIT = nsplit
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = torch.randn(M, K, generator=g).to(dev()); W = (torch.randn(N, K, generator=g) * 0.1).to(dev()); b = torch.randn(N, generator=g).to(dev())
+    ldn = (N + 3) // 4 * 4
+    dy = torch.zeros(M, ldn, device=dev()); dy[:, :N] = torch.randn(M, N, generator=g).to(dev())
+    outs = []
+    for wn in (8, 2):
+        y = torch.zeros(M, ldn, device=dev())
+        ops.gemm(ops.OP_KC, ops.OP_KC, x, K, W, K, y, ldn, M, N, K, bias=b, act=1, tile_wn=wn)
+        dx = torch.empty(M, K, device=dev())
+        ops.gemm(ops.OP_KC, ops.OP_RC, dy, ldn, W, K, dx, K, M, K, ldn, kb_valid=N, tile_wn=wn)
+        dW = torch.zeros(N, K, device=dev()); db = torch.zeros(N, device=dev())
+        ops.gemm(ops.OP_RC, ops.OP_RC, dy, ldn, x, K, dW, K, N, K, M, beta=1, rowsum_a=db, tile_wn=wn)
+        outs.append((y, dx, dW, db))
+    assert relerr(outs[0][0][:, :N], torch.relu(x.double().cpu() @ W.double().cpu().t() + b.double().cpu())) < TOL[nsplit]
+    assert relerr(outs[0][2], dy[:, :N].double().cpu().t() @ x.double().cpu()) < TOL[nsplit]
+    assert relerr(outs[0][3], dy[:, :N].double().cpu().sum(0)) < 1e-5
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])
+    config.NSPLIT = 3

@@ -5,7 +5,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunast_hip.so")
+LIB_PATH = os.environ.get("UNAST_HIP_LIB") or os.path.join(_HERE, "libunast_hip.so")   # override: kernel experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "unast_hip.h")
 
 _lib = None

@@ -13,3 +13,8 @@ def set_precision(name):
 
 def precision_name():
     return "bf16" if NSPLIT == 1 else "bf16x3"
+
+
+# Weights as GEMM B operands are read from a pre-split copy kept next to the flat parameter store (engine.FlatStore);
+# off = the kernels re-split the fp32 weights in every row panel (bit-identical results; for A/B timing only).
+PRESPLIT_WEIGHTS = os.environ.get("UNAST_PRESPLIT", "1") != "0"

@@ -76,6 +76,10 @@ __device__ __forceinline__ uint32_t pack_bf16_trunc(float a, float b) {
 }
 template <int NSPLIT>
 __device__ __forceinline__ void split4(const float4& v, u32x2& hi, u32x2& lo) {
+#ifdef UNAST_EXP_FAKE_SPLIT      // timing experiment only: no conversion work (wrong numerics)
+    hi[0] = __float_as_uint(v.x); hi[1] = __float_as_uint(v.y); lo[0] = __float_as_uint(v.z); lo[1] = __float_as_uint(v.w);
+    return;
+#endif
     hi[0] = pack_bf16_rne(v.x, v.y);
     hi[1] = pack_bf16_rne(v.z, v.w);
     if (NSPLIT == 1) {
@@ -88,6 +92,13 @@ __device__ __forceinline__ void split4(const float4& v, u32x2& hi, u32x2& lo) {
         lo[0] = pack_bf16_rne(rx, ry);
         lo[1] = pack_bf16_rne(rz, rw);
     }
+}
+// Pre-split operand chunk of 4 consecutive fp32 values: [hi0 hi1 | hi2 hi3 | lo0 lo1 | lo2 lo3] (bf16 pairs).  A tensor kept
+// in this format has the byte offsets of its fp32 original, so a GEMM loader reads it with the same addressing.
+__device__ __forceinline__ uint4 split_chunk(const float4& v) {
+    u32x2 hi, lo;
+    split4<3>(v, hi, lo);
+    return make_uint4(hi[0], hi[1], lo[0], lo[1]);
 }
 __device__ __forceinline__ float bf16_bits_to_float(unsigned short b) { return __uint_as_float(((uint32_t)b) << 16); }
 

@@ -95,187 +95,10 @@ __device__ __forceinline__ float4 load_rc(const GemmParams& p, const float* __re
     return v;
 }
 
-template <int AM, int BMODE, int NSPLIT, int WN, int WM>
-__global__ __launch_bounds__(64 * WM * WN, (WM == 4 ? 4 : 2)) void gemm_kernel(const GemmParams p) {
-    constexpr bool A_KC = (AM == OP_KC || AM == OP_KC_CONV);
-    constexpr bool B_KC = (BMODE == OP_KC);
-    constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
-    constexpr int NT = 64 * WM * WN;                   // threads
-    constexpr int MI = 8 / WM;                         // 16-row sub-tiles per wave along M (wave tile = 16*MI x 64)
-    constexpr int GBN = 64 * WN;                       // block tile columns
-    constexpr int A_BYTES = A_KC ? kc_bytes(GBM) : rc_bytes(GBM);
-    constexpr int B_BYTES = B_KC ? kc_bytes(GBN) : rc_bytes(GBN);
-    constexpr int A_RCS = rc_stride(GBM), B_RCS = rc_stride(GBN);
-    // loader geometry: K-contiguous: 8 threads per 128-B row piece; row-contiguous: ROWS/4 threads per k-row
-    constexpr int A_PASS = (GBM * 8) / NT, B_PASS = (GBN * 8) / NT;          // float4 per thread per tile
-    constexpr int KC_RPP = NT / 8;                                           // rows per pass (K-contiguous)
-    constexpr int A_TPK = GBM / 4, B_TPK = GBN / 4;                          // threads per k-row (row-contiguous)
-    constexpr int A_KPP = NT / A_TPK, B_KPP = NT / B_TPK;                    // k-rows per pass
-    constexpr int STAGE = (A_BYTES + B_BYTES) * PARTS;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];      // two stages: one barrier per k-step
-
-    // XCD-aware tile mapping: blocks b and b+8 (same XCD under round-robin dispatch) share the A row panel.
-    const int pid = blockIdx.x;
-    int tile_m, tile_n, zsplit = 0;
-    if (p.tiles_m >= 8 && p.nsplitk == 1) {
-        const int G = 8 * p.tiles_n;
-        const int grp = pid / G, rem = pid - grp * G;
-        tile_m = grp * 8 + (rem & 7);
-        tile_n = rem >> 3;
-    } else {
-        // few row panels (weight gradients, split-K): all tiles of one K-slice read the same operand rows, so they get
-        // linear ids that are equal mod 8 (same XCD / L2 under round-robin dispatch); grid padded to 8 slices.
-        const int ntile = p.tiles_m * p.tiles_n;
-        const int g8 = pid & 7, sidx = pid >> 3;
-        zsplit = (sidx / ntile) * 8 + g8;
-        const int tile = sidx % ntile;
-        tile_m = tile % p.tiles_m;
-        tile_n = tile / p.tiles_m;
-        if (zsplit >= p.nsplitk) return;
-    }
-    if (tile_m >= p.tiles_m) return;        // whole block exits together (keeps EXEC full for tr reads)
-    const int m0 = tile_m * GBM, n0 = tile_n * GBN;
-    const int kbeg = zsplit * p.kchunk;
-    const int kend = min(p.K, kbeg + p.kchunk);
-    const int nk = (kend - kbeg + GBK - 1) / GBK;
-
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int l15 = lane & 15, g = lane >> 4;
-
-    // ---- per-thread loader coordinates -------------------------------------------------------
-    int a_rb[A_PASS], a_rt[A_PASS];   // conv A: batch row base / time index of the tile rows of this thread
-#pragma unroll
-    for (int i = 0; i < A_PASS; ++i) { a_rb[i] = 0; a_rt[i] = 0; }
-    if (AM == OP_KC_CONV) {
-#pragma unroll
-        for (int i = 0; i < A_PASS; ++i) {
-            int row = min(m0 + (t >> 3) + KC_RPP * i, p.M - 1);     // clamped: loads are unconditional (rows >= M are zeroed after the load)
-            int b = row / p.T;
-            a_rb[i] = b * p.T;
-            a_rt[i] = row - b * p.T;
-        }
-    }
-    int b_cj = 0, b_cc = 0;                 // conv-wgrad B: tap and channel of this thread's 4 columns
-    if (BMODE == OP_RC_CONV_WGRAD) {
-        int row = min(n0 + (t % B_TPK) * 4, p.N - 4);       // clamped for the same reason (N = 5*cb is a multiple of 4)
-        b_cj = row / p.cb;
-        b_cc = row - b_cj * p.cb;
-    }
-
-    auto load_tiles = [&](int kt, float4 (&ra)[A_PASS], float4 (&rb)[B_PASS]) {
-        const int k0 = kbeg + kt * GBK;
-#pragma unroll
-        for (int i = 0; i < A_PASS; ++i) {
-            if (A_KC) ra[i] = load_kc<AM>(p, p.A, p.lda, p.M, m0 + (t >> 3) + KC_RPP * i, k0 + (t & 7) * 4, kend, a_rb[i], a_rt[i]);
-            else      ra[i] = load_rc<AM>(p, p.A, p.lda, p.M, m0 + (t % A_TPK) * 4, k0 + t / A_TPK + A_KPP * i, kend, p.K, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < B_PASS; ++i) {
-            if (B_KC) rb[i] = load_kc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t >> 3) + KC_RPP * i, k0 + (t & 7) * 4, kend, 0, 0);
-            else      rb[i] = load_rc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t % B_TPK) * 4, k0 + t / B_TPK + B_KPP * i, kend, p.kb_valid, b_cj, b_cc);
-        }
-    };
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool do_rowsum = (AM == OP_RC) && p.rowsum_a && tile_n == 0;
-    auto store_tiles = [&](const float4 (&ra)[A_PASS], const float4 (&rb)[B_PASS], unsigned char* sA, unsigned char* sB) {
-#pragma unroll
-        for (int i = 0; i < A_PASS; ++i) {
-            u32x2 hi, lo;
-            if (AM == OP_RC && do_rowsum) { bsum[0] += ra[i].x; bsum[1] += ra[i].y; bsum[2] += ra[i].z; bsum[3] += ra[i].w; }
-            split4<NSPLIT>(ra[i], hi, lo);
-            const int off = A_KC ? kc_off((t >> 3) + KC_RPP * i, (t & 7) * 4) : ((t / A_TPK + A_KPP * i) * A_RCS + (t % A_TPK) * 4) * 2;
-            *reinterpret_cast<u32x2*>(sA + off) = hi;
-            if (PARTS == 2) *reinterpret_cast<u32x2*>(sA + A_BYTES + off) = lo;
-        }
-#pragma unroll
-        for (int i = 0; i < B_PASS; ++i) {
-            u32x2 hi, lo;
-            split4<NSPLIT>(rb[i], hi, lo);
-            const int off = B_KC ? kc_off((t >> 3) + KC_RPP * i, (t & 7) * 4) : ((t / B_TPK + B_KPP * i) * B_RCS + (t % B_TPK) * 4) * 2;
-            *reinterpret_cast<u32x2*>(sB + off) = hi;
-            if (PARTS == 2) *reinterpret_cast<u32x2*>(sB + B_BYTES + off) = lo;
-        }
-    };
-    // MFMA operand fragment for the 16-row sub-tile starting at tile row `rbase`: lane holds [row l15][k 8g..8g+7]
-    auto frag = [&](const unsigned char* img, bool kc, int rcs, int rbase) -> bf16x8_t {
-        if (kc) {
-            int row = rbase + l15;
-            return *reinterpret_cast<const bf16x8_t*>(img + row * 64 + ((g ^ swz_h(row)) << 4));
-        } else {
-            const int q = l15 >> 2, pp = l15 & 3;
-            s16x4 v0 = lds_read_tr16(img + ((8 * g + q) * rcs + rbase + 4 * pp) * 2);
-            s16x4 v1 = lds_read_tr16(img + ((8 * g + 4 + q) * rcs + rbase + 4 * pp) * 2);
-            s16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            return __builtin_bit_cast(bf16x8_t, v);
-        }
-    };
-
-    f32x4 acc[MI][4];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto compute = [&](const unsigned char* sA, const unsigned char* sB) {
-        bf16x8_t af[MI][PARTS], bfr[4][PARTS];
-#pragma unroll
-        for (int s = 0; s < PARTS; ++s) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i][s] = frag(sA + s * A_BYTES, A_KC, A_RCS, wm * (16 * MI) + i * 16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bfr[i][s] = frag(sB + s * B_BYTES, B_KC, B_RCS, wn * 64 + i * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // swapped operands: the B tile is the MFMA "A" (rows = n), so each lane ends up with 4 consecutive n
-                if (NSPLIT == 3) {
-                    acc[i][j] = mfma16(bfr[j][PARTS - 1], af[i][0], acc[i][j]);
-                    acc[i][j] = mfma16(bfr[j][0], af[i][PARTS - 1], acc[i][j]);
-                }
-                acc[i][j] = mfma16(bfr[j][0], af[i][0], acc[i][j]);
-            }
-    };
-
-    // Two-stage software pipeline, one barrier per k-step.  In iteration kt a wave (1) issues the global loads of tile
-    // kt+2 into the register set that was drained one iteration ago, (2) multiplies tile kt from LDS stage kt%2 and, in
-    // the shadow of those MFMAs, converts tile kt+1 (whose loads were issued an iteration ago) and writes it to the
-    // other LDS stage.  Loads are issued unconditionally (clamped addresses) so the compiler's vmcnt counts are static.
-    float4 ra0[A_PASS], rb0[B_PASS], ra1[A_PASS], rb1[B_PASS];
-    unsigned char* const s0A = smem;
-    unsigned char* const s0B = smem + A_BYTES * PARTS;
-    unsigned char* const s1A = smem + STAGE;
-    unsigned char* const s1B = smem + STAGE + A_BYTES * PARTS;
-    load_tiles(0, ra0, rb0);
-    load_tiles(1, ra1, rb1);
-    store_tiles(ra0, rb0, s0A, s0B);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        load_tiles(kt + 2, ra0, rb0);
-        compute(s0A, s0B);
-        store_tiles(ra1, rb1, s1A, s1B);
-        __syncthreads();
-        if (kt + 1 < nk) {
-            load_tiles(kt + 3, ra1, rb1);
-            compute(s1A, s1B);
-            store_tiles(ra0, rb0, s0A, s0B);
-            __syncthreads();
-        }
-    }
-
-    if (AM == OP_RC && do_rowsum) {          // threads t, t+32, ... hold partial sums of rows m0 + 4*(t&31) .. +3
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);
-        if (t < 128) red[t] = 0.f;
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 4; ++c) atomicAdd(&red[(t % A_TPK) * 4 + c], bsum[c]);
-        __syncthreads();
-        if (t < 128 && m0 + t < p.M) atomicAdd(p.rowsum_a + m0 + t, red[t]);
-    }
+// Epilogue shared by the GEMM kernels: lane holds C[m = ..+l15][n = ..+4g .. 4g+3] of MI x 4 MFMA tiles; the wave's
+// sub-tile starts at (m0 + wm*16*MI, n0 + wn*64).
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][4], int m0, int n0, int wm, int wn, int l15, int g, int zsplit) {
     // ---- epilogue: lane holds C[m = ..+l15][n = ..+4g .. 4g+3] --------------------------------------
     const bool first_split = (zsplit == 0);
     if (p.slab) {                                   // split-K: raw partial sums to this split's slab (plain 16-B stores)
@@ -354,6 +177,245 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 ? 4 : 2)) void gemm_kernel(c
     }
 }
 
+// FLAGS bit 0 (FULL): every tile is interior (M % 128 == 0, N % tile == 0, K and the K-slices % 32 == 0, plain operands):
+//   loads carry no bounds handling and address as uniform base (advanced per k-step on the scalar unit) + a per-thread
+//   32-bit byte offset computed once -- the selects and 64-bit address arithmetic were a quarter of the loop's vector
+//   instructions, and this loop is bound by vector-instruction issue (MFMA issue + operand conversion), not by MFMA rate.
+// FLAGS bit 1 (BSPLIT): B is a weight kept in the pre-split chunk format (common.h split_chunk; written by the AdamW
+//   kernel): the loader copies hi/lo straight to LDS instead of re-splitting the same weights in every row panel.
+template <int AM, int BMODE, int NSPLIT, int WN, int WM, int FLAGS>
+__global__ __launch_bounds__(64 * WM * WN, (WM == 4 ? 4 : 2)) void gemm_kernel(const GemmParams p) {
+    constexpr bool FULL = (FLAGS & 1) != 0, BSPLIT = (FLAGS & 2) != 0;
+    static_assert(!FULL || ((AM == OP_KC || AM == OP_RC) && (BMODE == OP_KC || BMODE == OP_RC)), "FULL: plain operands only");
+    constexpr bool A_KC = (AM == OP_KC || AM == OP_KC_CONV);
+    constexpr bool B_KC = (BMODE == OP_KC);
+    constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
+    constexpr int NT = 64 * WM * WN;                   // threads
+    constexpr int MI = 8 / WM;                         // 16-row sub-tiles per wave along M (wave tile = 16*MI x 64)
+    constexpr int GBN = 64 * WN;                       // block tile columns
+    constexpr int A_BYTES = A_KC ? kc_bytes(GBM) : rc_bytes(GBM);
+    constexpr int B_BYTES = B_KC ? kc_bytes(GBN) : rc_bytes(GBN);
+    constexpr int A_RCS = rc_stride(GBM), B_RCS = rc_stride(GBN);
+    // loader geometry: K-contiguous: 8 threads per 128-B row piece; row-contiguous: ROWS/4 threads per k-row
+    constexpr int A_PASS = (GBM * 8) / NT, B_PASS = (GBN * 8) / NT;          // float4 per thread per tile
+    constexpr int KC_RPP = NT / 8;                                           // rows per pass (K-contiguous)
+    constexpr int A_TPK = GBM / 4, B_TPK = GBN / 4;                          // threads per k-row (row-contiguous)
+    constexpr int A_KPP = NT / A_TPK, B_KPP = NT / B_TPK;                    // k-rows per pass
+    constexpr int STAGE = (A_BYTES + B_BYTES) * PARTS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];      // two stages: one barrier per k-step
+
+    // XCD-aware tile mapping: blocks b and b+8 (same XCD under round-robin dispatch) share the A row panel.
+    const int pid = blockIdx.x;
+    int tile_m, tile_n, zsplit = 0;
+    if (p.tiles_m >= 8 && p.nsplitk == 1) {
+        const int G = 8 * p.tiles_n;
+        const int grp = pid / G, rem = pid - grp * G;
+        tile_m = grp * 8 + (rem & 7);
+        tile_n = rem >> 3;
+    } else {
+        // few row panels (weight gradients, split-K): all tiles of one K-slice read the same operand rows, so they get
+        // linear ids that are equal mod 8 (same XCD / L2 under round-robin dispatch); grid padded to 8 slices.
+        const int ntile = p.tiles_m * p.tiles_n;
+        const int g8 = pid & 7, sidx = pid >> 3;
+        zsplit = (sidx / ntile) * 8 + g8;
+        const int tile = sidx % ntile;
+        tile_m = tile % p.tiles_m;
+        tile_n = tile / p.tiles_m;
+        if (zsplit >= p.nsplitk) return;
+    }
+    if (tile_m >= p.tiles_m) return;        // whole block exits together (keeps EXEC full for tr reads)
+    const int m0 = tile_m * GBM, n0 = tile_n * GBN;
+    const int kbeg = zsplit * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk = (kend - kbeg + GBK - 1) / GBK;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    // ---- per-thread loader coordinates -------------------------------------------------------
+    int a_rb[A_PASS], a_rt[A_PASS];   // conv A: batch row base / time index of the tile rows of this thread
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) { a_rb[i] = 0; a_rt[i] = 0; }
+    if (AM == OP_KC_CONV) {
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            int row = min(m0 + (t >> 3) + KC_RPP * i, p.M - 1);     // clamped: loads are unconditional (rows >= M are zeroed after the load)
+            int b = row / p.T;
+            a_rb[i] = b * p.T;
+            a_rt[i] = row - b * p.T;
+        }
+    }
+    int b_cj = 0, b_cc = 0;                 // conv-wgrad B: tap and channel of this thread's 4 columns
+    if (BMODE == OP_RC_CONV_WGRAD) {
+        int row = min(n0 + (t % B_TPK) * 4, p.N - 4);       // clamped for the same reason (N = 5*cb is a multiple of 4)
+        b_cj = row / p.cb;
+        b_cc = row - b_cj * p.cb;
+    }
+
+    uint32_t a_off[A_PASS], b_off[B_PASS];          // FULL: per-thread byte offsets inside the current k-slab
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i)
+        a_off[i] = FULL ? 4u * (A_KC ? (uint32_t)(m0 + (t >> 3) + KC_RPP * i) * (uint32_t)p.lda + (t & 7) * 4
+                                     : (uint32_t)(t / A_TPK + A_KPP * i) * (uint32_t)p.lda + m0 + (t % A_TPK) * 4) : 0u;
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i)
+        b_off[i] = FULL ? 4u * (B_KC ? (uint32_t)(n0 + (t >> 3) + KC_RPP * i) * (uint32_t)p.ldb + (t & 7) * 4
+                                     : (uint32_t)(t / B_TPK + B_KPP * i) * (uint32_t)p.ldb + n0 + (t % B_TPK) * 4) : 0u;
+
+    auto load_tiles = [&](int kt, float4 (&ra)[A_PASS], float4 (&rb)[B_PASS]) {
+        if (FULL) {     // prefetches past the last k-step re-read the last one (never consumed) instead of leaving the operand
+            const size_t k0 = (size_t)(kbeg + min(kt, nk - 1) * GBK);
+            const char* Ab = reinterpret_cast<const char*>(p.A + (A_KC ? k0 : k0 * (size_t)p.lda));
+            const char* Bb = reinterpret_cast<const char*>(p.B + (B_KC ? k0 : k0 * (size_t)p.ldb));
+#pragma unroll
+            for (int i = 0; i < A_PASS; ++i) ra[i] = *reinterpret_cast<const float4*>(Ab + a_off[i]);
+#pragma unroll
+            for (int i = 0; i < B_PASS; ++i) rb[i] = *reinterpret_cast<const float4*>(Bb + b_off[i]);
+            return;
+        }
+        const int k0 = kbeg + kt * GBK;
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            if (A_KC) ra[i] = load_kc<AM>(p, p.A, p.lda, p.M, m0 + (t >> 3) + KC_RPP * i, k0 + (t & 7) * 4, kend, a_rb[i], a_rt[i]);
+            else      ra[i] = load_rc<AM>(p, p.A, p.lda, p.M, m0 + (t % A_TPK) * 4, k0 + t / A_TPK + A_KPP * i, kend, p.K, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+            if (B_KC) rb[i] = load_kc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t >> 3) + KC_RPP * i, k0 + (t & 7) * 4, kend, 0, 0);
+            else      rb[i] = load_rc<BMODE>(p, p.B, p.ldb, p.N, n0 + (t % B_TPK) * 4, k0 + t / B_TPK + B_KPP * i, kend, p.kb_valid, b_cj, b_cc);
+        }
+    };
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = (AM == OP_RC) && p.rowsum_a && tile_n == 0;
+    // `live`: the tile exists (FULL prefetches past the end re-read the last tile; the general path zero-fills them)
+    auto store_tiles = [&](const float4 (&ra)[A_PASS], const float4 (&rb)[B_PASS], unsigned char* sA, unsigned char* sB, bool live) {
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            u32x2 hi, lo;
+            if (AM == OP_RC && do_rowsum && live) { bsum[0] += ra[i].x; bsum[1] += ra[i].y; bsum[2] += ra[i].z; bsum[3] += ra[i].w; }
+            split4<NSPLIT>(ra[i], hi, lo);
+            const int off = A_KC ? kc_off((t >> 3) + KC_RPP * i, (t & 7) * 4) : ((t / A_TPK + A_KPP * i) * A_RCS + (t % A_TPK) * 4) * 2;
+            *reinterpret_cast<u32x2*>(sA + off) = hi;
+            if (PARTS == 2) *reinterpret_cast<u32x2*>(sA + A_BYTES + off) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+            u32x2 hi, lo;
+            if (BSPLIT) {
+                hi[0] = __float_as_uint(rb[i].x); hi[1] = __float_as_uint(rb[i].y);
+                lo[0] = __float_as_uint(rb[i].z); lo[1] = __float_as_uint(rb[i].w);
+            } else {
+                split4<NSPLIT>(rb[i], hi, lo);
+            }
+            const int off = B_KC ? kc_off((t >> 3) + KC_RPP * i, (t & 7) * 4) : ((t / B_TPK + B_KPP * i) * B_RCS + (t % B_TPK) * 4) * 2;
+            *reinterpret_cast<u32x2*>(sB + off) = hi;
+            if (PARTS == 2) *reinterpret_cast<u32x2*>(sB + B_BYTES + off) = lo;
+        }
+    };
+    // MFMA operand fragment for the 16-row sub-tile starting at tile row `rbase`: lane holds [row l15][k 8g..8g+7]
+    auto frag = [&](const unsigned char* img, bool kc, int rcs, int rbase) -> bf16x8_t {
+        if (kc) {
+            int row = rbase + l15;
+            return *reinterpret_cast<const bf16x8_t*>(img + row * 64 + ((g ^ swz_h(row)) << 4));
+        } else {
+            const int q = l15 >> 2, pp = l15 & 3;
+            s16x4 v0 = lds_read_tr16(img + ((8 * g + q) * rcs + rbase + 4 * pp) * 2);
+            s16x4 v1 = lds_read_tr16(img + ((8 * g + 4 + q) * rcs + rbase + 4 * pp) * 2);
+            s16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            return __builtin_bit_cast(bf16x8_t, v);
+        }
+    };
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](const unsigned char* sA, const unsigned char* sB) {
+        bf16x8_t af[MI][PARTS], bfr[4][PARTS];
+#pragma unroll
+        for (int s = 0; s < PARTS; ++s) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i][s] = frag(sA + s * A_BYTES, A_KC, A_RCS, wm * (16 * MI) + i * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bfr[i][s] = frag(sB + s * B_BYTES, B_KC, B_RCS, wn * 64 + i * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // swapped operands: the B tile is the MFMA "A" (rows = n), so each lane ends up with 4 consecutive n
+                if (NSPLIT == 3) {
+                    acc[i][j] = mfma16(bfr[j][PARTS - 1], af[i][0], acc[i][j]);
+                    acc[i][j] = mfma16(bfr[j][0], af[i][PARTS - 1], acc[i][j]);
+                }
+                acc[i][j] = mfma16(bfr[j][0], af[i][0], acc[i][j]);
+            }
+    };
+
+    // Two-stage software pipeline, one barrier per k-step.  In iteration kt a wave (1) issues the global loads of tile
+    // kt+2 into the register set that was drained one iteration ago, (2) multiplies tile kt from LDS stage kt%2 and, in
+    // the shadow of those MFMAs, converts tile kt+1 (whose loads were issued an iteration ago) and writes it to the
+    // other LDS stage.  Loads are issued unconditionally (clamped addresses) so the compiler's vmcnt counts are static.
+    float4 ra0[A_PASS], rb0[B_PASS], ra1[A_PASS], rb1[B_PASS];
+    unsigned char* const s0A = smem;
+    unsigned char* const s0B = smem + A_BYTES * PARTS;
+    unsigned char* const s1A = smem + STAGE;
+    unsigned char* const s1B = smem + STAGE + A_BYTES * PARTS;
+    load_tiles(0, ra0, rb0);
+    load_tiles(1, ra1, rb1);
+    store_tiles(ra0, rb0, s0A, s0B, true);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        load_tiles(kt + 2, ra0, rb0);
+        compute(s0A, s0B);
+        store_tiles(ra1, rb1, s1A, s1B, kt + 1 < nk);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            load_tiles(kt + 3, ra1, rb1);
+            compute(s1A, s1B);
+            store_tiles(ra0, rb0, s0A, s0B, kt + 2 < nk);
+            __syncthreads();
+        }
+    }
+
+    if (AM == OP_RC && do_rowsum) {          // threads t, t+32, ... hold partial sums of rows m0 + 4*(t&31) .. +3
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (t < 128) red[t] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) atomicAdd(&red[(t % A_TPK) * 4 + c], bsum[c]);
+        __syncthreads();
+        if (t < 128 && m0 + t < p.M) atomicAdd(p.rowsum_a + m0 + t, red[t]);
+    }
+    gemm_epilogue<MI>(p, acc, m0, n0, wm, wn, l15, g, zsplit);
+}
+
+// ---------------------------------------------------------------------------------------------
+// What bounds this kernel (MI355X, round-1 measurements; tools/make_gemm_variants.py, tools/make_gemm_stamps.py,
+// tools/mfma_peak.cpp, tools/pmc_gemm.sh; numbers in DESIGN.md section 4):
+//   * no compute unit is saturated: MFMA pipe 40 % busy by SQ_VALU_MFMA_BUSY_CYCLES (54 % of the 1.7-1.8 PFLOP/s this
+//     chip sustains on random bf16 data -- it holds ~1.7 GHz under MFMA load, not 2.4), LDS 30 %, TCP 30 %, zero LDS
+//     bank conflicts, vector issue < 50 %;
+//   * a "skeleton" build that only ISSUES the tile loads (6 of 24 MFMAs, no LDS traffic, no barrier, loaded data never
+//     waited for) still needs 0.55 us per k-step per workgroup and 1.13 us with two workgroups per CU, and 36 of the full
+//     kernel's 53 us at 25600x256x1024: the floor is the rate at which a CU pulls the fp32 operand slabs through its
+//     vector-memory path (~58 GB/s per CU, ~15 TB/s chip-wide from L2) on top of the HBM/MALL stream of A and C
+//     (131 MB per launch = 2.5 TB/s at 52 us).  With fp32 activations and 3 MFMAs per product these d=256 contractions
+//     sit below the ridge point (~300 FLOP/B vs ~450), i.e. they are bandwidth-bound, not MFMA-bound;
+//   * three restructurings of the main loop were built, verified bit-identical and measured SLOWER than this kernel at
+//     25600x256x1024 (52 us): an explicit ping-pong split of the workgroup (one half multiplies while the other stages;
+//     85 us), an "A-direct" kernel whose waves load their A fragments straight from global memory into registers
+//     (32x128 wave tiles, B alone in LDS; 67 us) and a fully software-pipelined 3-stage version of this kernel (fragments
+//     of tile kt+1 read during the MFMAs of tile kt; 72 us).  Padding the row strides away from powers of two changes
+//     nothing (no channel camping).  What helped: the interior fast path and pre-split weights below (-7 % of GEMM time).
+// The remaining lever is fewer operand bytes per FLOP (wider tiles for N >= 512, fusing producer epilogues), not more
+// MFMA overlap.
+
 // C[m][n] (+)= sum_z slab[z][m][n]: reduction of the split-K partial slabs (plain streaming reads, deterministic order).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, size_t slab_stride, int ld_slab, int nsplit,
                                                             float* __restrict__ C, int ldc, int M, int N, int beta) {
@@ -378,18 +440,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------
 // Host launcher / C ABI
 // ---------------------------------------------------------------------------------------------
-template <int AM, int BMODE>
-static void launch_split(const GemmParams& p, int nsplit, int wn, dim3 grid, hipStream_t s) {
+template <int AM, int BMODE, int FLAGS>
+static void launch_tile(const GemmParams& p, int nsplit, int wn, dim3 grid, hipStream_t s) {
     if (wn == 4) {
-        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 4, 2>), grid, dim3(512), 0, s, p);
-        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 4, 2>), grid, dim3(512), 0, s, p);
+        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 4, 2, FLAGS>), grid, dim3(512), 0, s, p);
+        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 4, 2, FLAGS>), grid, dim3(512), 0, s, p);
     } else if (wn == 8) {      // 128x128 tile, 8 waves (4 along M x 2 along N): <=128 VGPRs, 4 waves/SIMD
-        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 2, 4>), grid, dim3(512), 0, s, p);
-        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 2, 4>), grid, dim3(512), 0, s, p);
+        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 2, 4, FLAGS>), grid, dim3(512), 0, s, p);
+        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 2, 4, FLAGS>), grid, dim3(512), 0, s, p);
     } else {
-        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 2, 2>), grid, dim3(256), 0, s, p);
-        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 2, 2>), grid, dim3(256), 0, s, p);
+        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 2, 2, FLAGS>), grid, dim3(256), 0, s, p);
+        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 2, 2, FLAGS>), grid, dim3(256), 0, s, p);
     }
+}
+// The fast-path variants exist for the tile each operand form runs with by default (8 waves for forward / dgrad, 4 waves
+// for weight gradients); any other request falls back to the general kernel (flags & ~1) -- never to a wrong one.
+template <int AM, int BMODE, bool WEIGHT_B, bool PLAIN>
+static void launch_split(const GemmParams& p, int nsplit, int wn, int flags, dim3 grid, hipStream_t s) {
+    const bool fast_tile = (AM == OP_RC) ? (wn == 2) : (wn == 8);
+    if constexpr (PLAIN) {
+        if (fast_tile && (flags & 1)) {
+            if constexpr (WEIGHT_B) { if (flags & 2) { launch_tile<AM, BMODE, 3>(p, nsplit, wn, grid, s); return; } }
+            launch_tile<AM, BMODE, 1>(p, nsplit, wn, grid, s);
+            return;
+        }
+    }
+    if constexpr (WEIGHT_B) { if (flags & 2) { launch_tile<AM, BMODE, 2>(p, nsplit, wn, grid, s); return; } }
+    launch_tile<AM, BMODE, 0>(p, nsplit, wn, grid, s);
 }
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -401,8 +478,10 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
                           const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale,
                           float alpha, int beta, int act,
                           float drop_p, unsigned int seed, unsigned int stream_id,
-                          int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, int tile_wn, hipStream_t stream) {
+                          int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, int tile_wn, int b_presplit,
+                          hipStream_t stream) {
     UNAST_REQUIRE(A && B && C, "unast_gemm: null operand");
+    UNAST_REQUIRE(!b_presplit || (a_mode == OP_KC || a_mode == OP_KC_CONV), "unast_gemm: a pre-split B is a weight (forward / dgrad forms only)");
     UNAST_REQUIRE(M > 0 && N > 0 && K > 0, "unast_gemm: bad dims M=%d N=%d K=%d", M, N, K);
     UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_gemm: nsplit must be 1 or 3");
     UNAST_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C), "unast_gemm: operands must be 16-byte aligned");
@@ -459,13 +538,22 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     if (b_mode == OP_RC_CONV_DGRAD) UNAST_REQUIRE(K == 5 * conv_cb, "unast_gemm: bad conv dgrad geometry");
     if (b_mode == OP_RC_CONV_WGRAD) UNAST_REQUIRE((conv_cb & 3) == 0 && N == 5 * conv_cb && K % p.T == 0, "unast_gemm: bad conv wgrad geometry");
     p.nsplitk = splitk;
+    // interior-only fast path (FLAGS bit 0): see gemm_kernel
+    int flags = b_presplit ? 2 : 0;
+    {
+        const bool plain = (a_mode == OP_KC || a_mode == OP_RC) && (b_mode == OP_KC || b_mode == OP_RC);
+        const uint64_t a_span = a_kc ? (uint64_t)M * lda * 4 : (uint64_t)(GBK + 1) * lda * 4 + (uint64_t)M * 4;
+        const uint64_t b_span = b_kc ? (uint64_t)N * ldb * 4 : (uint64_t)(GBK + 1) * ldb * 4 + (uint64_t)N * 4;
+        if (plain && M % GBM == 0 && N % gbn == 0 && K % GBK == 0 && kb_valid == K && a_span < (1ull << 32) && b_span < (1ull << 32))
+            flags |= 1;
+    }
     dim3 grid((p.tiles_m >= 8 && splitk == 1) ? ((p.tiles_m + 7) / 8) * 8 * p.tiles_n : ((splitk + 7) / 8) * 8 * p.tiles_m * p.tiles_n, 1, 1);
-    if (a_mode == OP_KC && b_mode == OP_KC) launch_split<OP_KC, OP_KC>(p, nsplit, wn, grid, stream);
-    else if (a_mode == OP_KC && b_mode == OP_RC) launch_split<OP_KC, OP_RC>(p, nsplit, wn, grid, stream);
-    else if (a_mode == OP_RC && b_mode == OP_RC) launch_split<OP_RC, OP_RC>(p, nsplit, wn, grid, stream);
-    else if (a_mode == OP_KC_CONV && b_mode == OP_KC) launch_split<OP_KC_CONV, OP_KC>(p, nsplit, wn, grid, stream);
-    else if (a_mode == OP_KC_CONV && b_mode == OP_RC_CONV_DGRAD) launch_split<OP_KC_CONV, OP_RC_CONV_DGRAD>(p, nsplit, wn, grid, stream);
-    else if (a_mode == OP_RC && b_mode == OP_RC_CONV_WGRAD) launch_split<OP_RC, OP_RC_CONV_WGRAD>(p, nsplit, wn, grid, stream);
+    if (a_mode == OP_KC && b_mode == OP_KC) launch_split<OP_KC, OP_KC, true, true>(p, nsplit, wn, flags, grid, stream);
+    else if (a_mode == OP_KC && b_mode == OP_RC) launch_split<OP_KC, OP_RC, true, true>(p, nsplit, wn, flags, grid, stream);
+    else if (a_mode == OP_RC && b_mode == OP_RC) launch_split<OP_RC, OP_RC, false, true>(p, nsplit, wn, flags, grid, stream);
+    else if (a_mode == OP_KC_CONV && b_mode == OP_KC) launch_split<OP_KC_CONV, OP_KC, true, false>(p, nsplit, wn, flags, grid, stream);
+    else if (a_mode == OP_KC_CONV && b_mode == OP_RC_CONV_DGRAD) launch_split<OP_KC_CONV, OP_RC_CONV_DGRAD, true, false>(p, nsplit, wn, flags, grid, stream);
+    else if (a_mode == OP_RC && b_mode == OP_RC_CONV_WGRAD) launch_split<OP_RC, OP_RC_CONV_WGRAD, false, false>(p, nsplit, wn, flags, grid, stream);
     else return unast_set_error(UNAST_ERR_ARG, "unast_gemm: unsupported operand mode pair (%d,%d)", a_mode, b_mode);
     if (p.slab) {
         size_t work = (size_t)M * (p.ld_slab / 4);

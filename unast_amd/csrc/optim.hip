@@ -21,9 +21,11 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
+// n4 float4 groups (+ a scalar tail).  split_out (optional): the updated parameters again in the GEMM's pre-split operand
+// format -- per 4 consecutive elements one 16-B chunk [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] of bf16 (same byte offsets as fp32).
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                    size_t n, const double* __restrict__ sumsq, float max_norm, float lr, float b1, float b2,
-                                                    float eps, float wd, float bc1, float bc2_sqrt) {
+                                                    size_t n4, size_t n, const double* __restrict__ sumsq, float max_norm, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float* __restrict__ split_out) {
     float coef = 1.f;
     if (max_norm > 0.f) {
         const float total = (float)sqrt(sumsq[0]);
@@ -31,16 +33,33 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
     const float decay = 1.f - lr * wd;
     const float step = lr / bc1;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float gg = g[i] * coef;
-        float pp = p[i] * decay;
-        float mm = m[i];
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        gg *= coef;
+        pp *= decay;
         mm = mm + (gg - mm) * (1.f - b1);
-        const float vv = v[i] * b2 + (1.f - b2) * gg * gg;
+        vv = vv * b2 + (1.f - b2) * gg * gg;
         const float denom = sqrtf(vv) / bc2_sqrt + eps;
         pp = pp - step * (mm / denom);
-        p[i] = pp; m[i] = mm; v[i] = vv;
+    };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 P = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+        const float4 G = reinterpret_cast<const float4*>(g)[i];
+        upd(P.x, G.x, M.x, V.x); upd(P.y, G.y, M.y, V.y); upd(P.z, G.z, M.z, V.z); upd(P.w, G.w, M.w, V.w);
+        reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
+        if (split_out) reinterpret_cast<uint4*>(split_out)[i] = split_chunk(P);
     }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+            float pp = p[i], mm = m[i], vv = v[i];
+            upd(pp, g[i], mm, vv);
+            p[i] = pp; m[i] = mm; v[i] = vv;
+        }
+}
+
+// dst = src in the pre-split operand format (see adamw_kernel); n4 chunks of 4 elements.
+__global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        reinterpret_cast<uint4*>(dst)[i] = split_chunk(reinterpret_cast<const float4*>(src)[i]);
 }
 
 extern "C" int unast_sumsq(const float* g, int64_t n, double* out, hipStream_t stream) {
@@ -54,14 +73,26 @@ extern "C" int unast_sumsq(const float* g, int64_t n, double* out, hipStream_t s
 }
 
 extern "C" int unast_adamw(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
-                           float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream) {
+                           float beta1, float beta2, float eps, float weight_decay, int step, float* split_out, hipStream_t stream) {
     UNAST_REQUIRE(p && g && m && v && n > 0 && step >= 1, "unast_adamw: bad arguments");
     UNAST_REQUIRE(!(max_norm > 0.f) || sumsq, "unast_adamw: clipping needs the sum-of-squares scalar");
+    UNAST_REQUIRE(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0, "unast_adamw: buffers must be 16-byte aligned");
+    UNAST_REQUIRE(!split_out || ((((uintptr_t)split_out) & 15) == 0 && (n & 3) == 0), "unast_adamw: split_out needs 16-byte alignment and n %% 4 == 0");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    size_t blocks = ((size_t)n + 255) / 256;
+    size_t blocks = ((size_t)n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, (size_t)n, sumsq, max_norm, lr, beta1, beta2, eps,
-                       weight_decay, (float)bc1, (float)sqrt(bc2));
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, (size_t)n / 4, (size_t)n, sumsq, max_norm, lr, beta1,
+                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), split_out);
     return unast_check_launch("unast_adamw");
+}
+
+extern "C" int unast_split_f32(const float* src, float* dst, int64_t n, hipStream_t stream) {
+    UNAST_REQUIRE(src && dst && n > 0 && (n & 3) == 0, "unast_split_f32: need n %% 4 == 0 (n=%lld)", (long long)n);
+    UNAST_REQUIRE(((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "unast_split_f32: buffers must be 16-byte aligned");
+    size_t blocks = ((size_t)n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, (size_t)n / 4);
+    return unast_check_launch("unast_split_f32");
 }

@@ -161,9 +161,29 @@ class FlatStore:
                 p.data = ph
                 self.gphys[n] = self.grad[o:o + k].view(p.shape)
             self.phys[n] = ph
+        # the weights once more in the GEMM's pre-split operand format (same byte offsets; refreshed by the AdamW kernel)
+        self.flat_split = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self._split_ver = None
+        ops.register_weight_span(self.flat.data_ptr(), self.total * 4, self.flat_split.data_ptr())
         self.dummy = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)   # forces autograd to call our backward
         self.touched = set()           # regions that received gradients since the last zero_grad
         self.grads_exposed = False
+
+    def __del__(self):
+        try:
+            ops.unregister_weight_span(self.flat.data_ptr())
+        except Exception:
+            pass
+
+    def sync_split(self):
+        """Re-split the weights if any parameter was written through torch since the last look (load_state_dict, manual
+        edits: they bump the parameter's version counter; the AdamW kernel updates both copies itself)."""
+        ver = 0
+        for p in self.params.values():
+            ver += p._version
+        if ver != self._split_ver:
+            ops.split_f32(self.flat, self.flat_split)
+            self._split_ver = ver
 
     # combined operands ---------------------------------------------------------------------------------------
     def span(self, first, last, shape, grad=False):

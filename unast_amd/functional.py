@@ -21,6 +21,7 @@ class Ctx:
 
     def __init__(self, store, training, seed):
         self.st = store
+        store.sync_split()
         self.P = store.phys
         self.training = training
         self.stochastic = training and not is_deterministic()      # dropout sites active

@@ -32,6 +32,26 @@ def _f32(t, name):
         raise TypeError("%s must be a float32 CUDA tensor (got %s on %s)" % (name, t.dtype, t.device))
 
 
+# Flat parameter stores whose weights also exist in the pre-split operand format: (base address, bytes, split base).
+_WEIGHT_SPANS = []
+
+
+def register_weight_span(base_ptr, nbytes, split_ptr):
+    _WEIGHT_SPANS[:] = [s for s in _WEIGHT_SPANS if s[0] != base_ptr]
+    _WEIGHT_SPANS.append((base_ptr, nbytes, split_ptr))
+
+
+def unregister_weight_span(base_ptr):
+    _WEIGHT_SPANS[:] = [s for s in _WEIGHT_SPANS if s[0] != base_ptr]
+
+
+def _presplit_ptr(ptr):
+    for base, nbytes, split in _WEIGHT_SPANS:
+        if base <= ptr < base + nbytes:
+            return split + (ptr - base)
+    return 0
+
+
 def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bias=None, R=None, ldr=0, G=None,
          ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False, rowsum_a=None, kb_valid=0, tile_wn=0):
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (R, "R"), (G, "G")):
@@ -40,9 +60,15 @@ def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bia
     if splitk > 1 and not atomic:
         ws_n = splitk * M * ((N + 3) // 4 * 4)
         ws = torch.empty(ws_n, dtype=torch.float32, device=C.device)          # split-K partial slabs (caching allocator)
-    check(lib().unast_gemm(a_mode, b_mode, nsplit or config.NSPLIT, _p(A), lda, _p(B), ldb, _p(C), ldc, M, N, K, kb_valid,
+    bp, presplit = _p(B), 0
+    if _WEIGHT_SPANS and config.PRESPLIT_WEIGHTS and a_mode != OP_RC:      # forward / dgrad forms: B may be a stored weight
+        sp = _presplit_ptr(bp)
+        if sp:
+            bp, presplit = sp, 1
+    check(lib().unast_gemm(a_mode, b_mode, nsplit or config.NSPLIT, _p(A), lda, bp, ldb, _p(C), ldc, M, N, K, kb_valid,
                            conv[0], conv[1], conv[2], conv[3], _p(bias), _p(R), ldr, _p(G), ldg, gate_scale,
-                           alpha, beta, act, drop_p, seed & 0xFFFFFFFF, stream_id, splitk, _p(ws), ws_n, _p(rowsum_a), tile_wn, _stream()), "unast_gemm")
+                           alpha, beta, act, drop_p, seed & 0xFFFFFFFF, stream_id, splitk, _p(ws), ws_n, _p(rowsum_a), tile_wn, presplit,
+                           _stream()), "unast_gemm")
 
 
 SPLITK_TARGET_BLOCKS = 320
@@ -297,6 +323,11 @@ def sumsq(g, out):
     check(lib().unast_sumsq(_p(g), g.numel(), _p(out), _stream()), "unast_sumsq")
 
 
-def adamw(p, g, m, v, sumsq_scalar, max_norm, lr, beta1, beta2, eps, wd, step):
-    check(lib().unast_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq_scalar), max_norm, lr, beta1, beta2, eps, wd, step, _stream()),
-          "unast_adamw")
+def adamw(p, g, m, v, sumsq_scalar, max_norm, lr, beta1, beta2, eps, wd, step, split_out=None):
+    check(lib().unast_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq_scalar), max_norm, lr, beta1, beta2, eps, wd, step,
+                            _p(split_out), _stream()), "unast_adamw")
+
+
+def split_f32(src, dst):
+    """dst = src in the GEMM's pre-split operand format (16-B chunks [hi x4 | lo x4] of bf16; same byte offsets)."""
+    check(lib().unast_split_f32(_p(src), _p(dst), src.numel(), _stream()), "unast_split_f32")

@@ -646,7 +646,7 @@ class FusedAdamW(torch.optim.Optimizer):
         for a, b in ranges:
             self._steps[(a, b)] += 1
             ops.adamw(st.flat[a:b], st.grad[a:b], self._m[a:b], self._v[a:b], self._ss, float(max_norm), float(g["lr"]),
-                      g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps[(a, b)])
+                      g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps[(a, b)], split_out=st.flat_split[a:b])
 
     def zero_grad(self, set_to_none=True):
         self.model._store().zero_grad()
