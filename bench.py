@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 # dense bf16 MFMA peak and HBM peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
 PEAK_MFMA_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
+SUSTAINED_MFMA_TFLOPS = 1800.0          # v_mfma_f32_16x16x32_bf16 on random data, all SIMDs busy: 9.2 ns per MFMA per SIMD (tools/mfma_peak.cpp)
 
 WORKLOADS = {
     # name: (B, Tt, Tm, L, use_discriminator)
@@ -65,8 +66,10 @@ class OpTimer:
 
     def _key(self, n, a, k):
         if n == "gemm":
-            # (a_mode, b_mode, M, N, K)
-            return (a[0], a[1], a[8], a[9], a[10])
+            # (a_mode, b_mode, M, N, K, conv channels of A / B, extra [M,N] operands read by the epilogue: R, G, C if beta)
+            conv = k.get("conv", (0, 0, 0, 0))
+            extra = int(k.get("R") is not None) + int(k.get("G") is not None) + int(bool(k.get("beta", 0)))
+            return (a[0], a[1], a[8], a[9], a[10], conv[1], conv[2], extra)
         if n in ("attn_fwd", "attn_bwd"):
             idx = 6 if n == "attn_fwd" else 11
             return tuple(int(x) for x in a[idx:idx + 5])          # B, H, Tq, Tk, causal
@@ -88,8 +91,18 @@ class OpTimer:
 
 
 def gemm_flops(key):
-    _, _, M, N, K = key
+    M, N, K = key[2:5]
     return 2.0 * M * N * K
+
+
+def gemm_bytes(key):
+    """Algorithmic HBM bytes of one contraction (every fp32 operand element read once, every output
+    element written once): A + B + C, plus the [M,N] operands the epilogue reads (residual, gate, C when accumulating).
+    Implicit-GEMM convolutions count the activation once (rows x channels), not once per tap."""
+    a_mode, b_mode, M, N, K, ca, cb, extra = key
+    a_el = M * ca if a_mode == 1 else M * K            # OP_KC_CONV: the [B*T, Cin] input
+    b_el = K * cb if b_mode == 4 else N * K            # OP_RC_CONV_WGRAD: the [B*T, Cin] input
+    return 4.0 * (a_el + b_el + M * N * (1 + extra))
 
 
 def attn_flops(name, key):
@@ -154,6 +167,10 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default=os.environ.get("UNAST_PREC", "bf16x3"), choices=["bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cm-steps", type=int, default=0, help="add this many cross-model (back-translation) sub-steps per step; reported "
+                    "separately from the headline metric, which is defined with cm_steps = 0 (SURVEY.md section 8d)")
+    ap.add_argument("--cm-max-len", type=int, default=0, help="cap of the autoregressive generation inside the cm sub-step (0 = reference "
+                    "defaults 815 mel frames / 300 tokens)")
     ap.add_argument("--profile-ops", action="store_true", help="time every op family (adds event overhead; not for the headline number)")
     ap.add_argument("--backend", default=os.environ.get("UNAST_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) is the product path; gloo only rehearses the multi-rank logic on a 1-GPU box")
@@ -183,7 +200,7 @@ def main():
     from unast_amd.configs import make_args
     config.set_precision(a.precision)
     B, Tt, Tm, L, use_disc = WORKLOADS[a.workload]
-    args = make_args(num_layers=L, ae_steps=1, sp_steps=1, d_steps=1, cm_steps=0, use_discriminator=use_disc)
+    args = make_args(num_layers=L, ae_steps=1, sp_steps=1, d_steps=1, cm_steps=a.cm_steps, use_discriminator=use_disc)
     train.DEVICE = dev
     utils.set_seed(1234)                      # identical random-init weights on every rank
     utils.set_deterministic(False)
@@ -191,7 +208,11 @@ def main():
     utils.set_seed(1234 + rank)               # per-rank dropout / noise / permutation streams
     batch = make_batch(B, Tt, Tm, seed=rank)
     batch = tuple(t.to(dev) for t in batch)   # inputs resident in HBM before the timed region
-    batches = dict(unsup=[batch], sup=[batch], disc=[batch])
+    batches = dict(unsup=[batch], sup=[batch], disc=[batch], cm=[batch] * a.cm_steps)
+    if a.cm_steps and a.cm_max_len:
+        orig_s, orig_t = model.speech_m.infer_sequence, model.text_m.infer_sequence
+        model.speech_m.infer_sequence = lambda memory, masks, max_len=a.cm_max_len: orig_s(memory, masks, max_len)
+        model.text_m.infer_sequence = lambda memory, masks, max_len=a.cm_max_len: orig_t(memory, masks, max_len)
     losses = defaultdict(list)
 
     def one_step(i):
@@ -239,26 +260,53 @@ def main():
         calls = sum(v[0] for v in summ[n].values())
         tot = sum(v[1] for v in summ[n].values())
         fl = sum((gemm_flops(k) if n == "gemm" else attn_flops(n, k)) * v[0] for k, v in summ[n].items())
-        fam[n] = dict(calls=calls, ms=tot, flops=fl)
+        fam[n] = dict(calls=calls, ms=tot, flops=fl, bytes=(sum(gemm_bytes(k) * v[0] for k, v in summ[n].items()) if n == "gemm" else 0.0))
     dom = max(fam, key=lambda n: fam[n]["ms"])
     d = fam[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     kernel_name = {"gemm": "gemm_kernel<*,*,%d> (all linear/conv contractions)" % config.NSPLIT,
                    "attn_fwd": "attn_q_kernel<%d,0>" % config.NSPLIT, "attn_bwd": "attn_q_kernel<%d,1> + attn_dkv_kernel<%d>" % (config.NSPLIT, config.NSPLIT)}[dom]
-    roofline = {"kernel": kernel_name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
-                "launches_per_step": d["calls"] / a.steps, "avg_launch_us": round(d["ms"] * 1e3 / max(d["calls"], 1), 2),
-                "mfma_issue_frac": round(ach * config.NSPLIT / PEAK_MFMA_BF16_TFLOPS, 4),
-                "note": "achieved = algorithmic FLOPs (2MNK per contraction; 4*B*H*Tq*Tk*64 per attention forward, x2.5 backward) / HIP-event time of "
-                        "these launches inside the timed region; each algorithmic product costs %d bf16 MFMAs in %s mode (mfma_issue_frac counts them)" % (config.NSPLIT, a.precision),
-                "families_ms_per_step": {n: round(fam[n]["ms"] / a.steps, 3) for n in fam}}
+    if dom == "gemm":
+        # The d=256 contractions are priced against HBM: with fp32 activations and 3 MFMAs per product they sit below the ridge
+        # point, the MFMA pipe is 40 % busy (rocprofv3 PMC) and a load-only build of the kernel already takes 70 % of its time
+        # (csrc/gemm.hip).  The MFMA view is kept beside it.
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+        traffic = None
+        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+        if a.workload == "c3" and config.NSPLIT == 3 and os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                g = [v for k, v in tj["kernels"].items() if "gemm_kernel" in k]
+                traffic = round(sum(v["hbm_MB_per_launch"] * v["launches"] for v in g) / sum(v["launches"] for v in g) * 1e6, 0)
+            except Exception:
+                traffic = None
+        roofline = {"kernel": kernel_name, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["calls"], 1), 0),
+                    "launches_per_step": d["calls"] / a.steps, "avg_launch_us": round(d["ms"] * 1e3 / max(d["calls"], 1), 2),
+                    "mfma_view": {"achieved_tflops": round(ach, 2), "frac_of_2500_dense_bf16": round(ach / PEAK_MFMA_BF16_TFLOPS, 4),
+                                  "mfma_issue_tflops": round(ach * config.NSPLIT, 1), "sustained_mfma_peak_measured_tflops": SUSTAINED_MFMA_TFLOPS},
+                    "note": "achieved = algorithmic bytes (fp32 A + B + C and epilogue operands, each once; conv inputs once, not per tap) / HIP-event "
+                            "time of these launches inside the timed region; traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE per launch from "
+                            "profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 passes of this command), null if that file is absent; mfma_view: 2MNK "
+                            "FLOPs per contraction, each product costs %d bf16 MFMAs in %s mode; sustained peak = tools/mfma_peak.cpp on this chip" % (config.NSPLIT, a.precision),
+                    "families_ms_per_step": {n: round(fam[n]["ms"] / a.steps, 3) for n in fam}}
+    else:
+        roofline = {"kernel": kernel_name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": d["calls"] / a.steps, "avg_launch_us": round(d["ms"] * 1e3 / max(d["calls"], 1), 2),
+                    "mfma_issue_frac": round(ach * config.NSPLIT / PEAK_MFMA_BF16_TFLOPS, 4),
+                    "note": "achieved = algorithmic FLOPs (4*B*H*Tq*Tk*64 per attention forward, x2.5 backward) / HIP-event time of these launches "
+                            "inside the timed region; each product costs %d bf16 MFMAs in %s mode" % (config.NSPLIT, a.precision),
+                    "families_ms_per_step": {n: round(fam[n]["ms"] / a.steps, 3) for n in fam}}
     out = {"metric": "mel-frames/sec/node (train step, gen+disc) at B=32,T_mel=800; 1/2/4/8-GPU scaling",
            "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16x3" if config.NSPLIT == 3 else "bf16", "data": "synthetic",
            "dist_backend": (a.backend if world > 1 else None),
            "config": {"workload": "%s: full adversarial gen+disc train step (AE+SP+clip/AdamW, D step+clip/AdamW), per-GPU B=%d, T_text=%d, T_mel=%d, "
-                                  "num_layers=%d, d=256, 4 heads, FFN 1024, 2x bi-LSTM(64) discriminator, dropout/noise/SpecAugment active" % (a.workload, B, Tt, Tm, L),
+                                  "num_layers=%d, d=256, 4 heads, FFN 1024, 2x bi-LSTM(64) discriminator, dropout/noise/SpecAugment active%s" % (
+                                      a.workload, B, Tt, Tm, L, (" + %d cross-model sub-step(s) with K/V-cached generation (NOT the headline configuration)" % a.cm_steps) if a.cm_steps else ""),
                       "global_batch": B * world, "parallelism": "dp%d" % world,
                       "precision": "split-bf16 (hi/lo) MFMA operands, fp32 accumulate and fp32 activations" if config.NSPLIT == 3 else "bf16 MFMA operands, fp32 accumulate"},
            "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),

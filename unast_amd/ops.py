@@ -71,8 +71,9 @@ def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bia
                            _stream()), "unast_gemm")
 
 
-SPLITK_TARGET_BLOCKS = 320
-SPLITK_MIN_KSTEPS = 10
+import os as _os
+SPLITK_TARGET_BLOCKS = int(_os.environ.get("UNAST_SPLITK_TARGET", "320"))
+SPLITK_MIN_KSTEPS = int(_os.environ.get("UNAST_SPLITK_MINK", "10"))
 
 
 def _splitk_for(M, N, K):
