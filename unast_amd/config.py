@@ -18,3 +18,8 @@ def precision_name():
 # Weights as GEMM B operands are read from a pre-split copy kept next to the flat parameter store (engine.FlatStore);
 # off = the kernels re-split the fp32 weights in every row panel (bit-identical results; for A/B timing only).
 PRESPLIT_WEIGHTS = os.environ.get("UNAST_PRESPLIT", "1") != "0"
+
+# Inside the train-step functions the text side, the speech side and the discriminator run on three HIP streams (their
+# launches under-fill the chip one at a time); 0 = everything on the caller's stream.  Direct calls of model methods outside
+# those functions are always single-stream.
+SIDE_STREAMS = os.environ.get("UNAST_SIDE_STREAMS", "1") != "0"

@@ -19,6 +19,103 @@ from . import ops
 ALIGN = 64  # floats (256 B) between parameter starts
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Side streams: text side / speech side / discriminator as three HIP streams inside one train step
+# ---------------------------------------------------------------------------------------------------------------
+class _Streams:
+    enabled = False      # inside `with side_streams():`
+    pool = {}            # (device index, name) -> torch.cuda.Stream
+    producer = {}        # storage address -> (stream name, event recorded after the producing call); views share the storage
+    used = set()
+
+
+def _side(name):
+    key = (torch.cuda.current_device(), name)
+    s = _Streams.pool.get(key)
+    if s is None:
+        s = _Streams.pool[key] = torch.cuda.Stream()
+    return s
+
+
+def _tensors(obj, out):
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            out.append(obj)
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            _tensors(o, out)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _tensors(o, out)
+    return out
+
+
+class side_streams:
+    """Context of one train sub-step: while it is active, calls decorated with `on_stream(name)` run on their own HIP stream
+    and only wait for the streams that produced their inputs.  Leaving it joins every side stream into the current one."""
+
+    def __enter__(self):
+        from . import config
+        self.active = config.SIDE_STREAMS and not _Streams.enabled and torch.cuda.is_available()
+        if self.active:
+            _Streams.enabled = True
+            _Streams.producer.clear()
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            join_streams()
+            _Streams.enabled = False
+            _Streams.producer.clear()
+
+
+def join_streams():
+    """The current stream waits for everything enqueued on the side streams (before torch ops that read their results,
+    before the optimizer).  Host-side cost only: no device synchronisation."""
+    if not _Streams.used:
+        return
+    cur = torch.cuda.current_stream()
+    for name in _Streams.used:
+        s = _side(name)
+        if s != cur:
+            cur.wait_stream(s)
+    if not _Streams.enabled:
+        _Streams.used.clear()
+
+
+def on_stream(name):
+    """Decorator: inside `side_streams()` the call runs on the side stream `name` after waiting for (a) everything enqueued on
+    the caller's stream so far and (b) the side streams that produced any tensor argument (tracked by storage, so views and
+    permutes keep their producer).  Cross-stream arguments are handed to the caching allocator with record_stream."""
+    def deco(fn):
+        def wrapper(*args, **kw):
+            if not _Streams.enabled:
+                return fn(*args, **kw)
+            cur = torch.cuda.current_stream()
+            s = _side(name)
+            if cur == s:
+                return fn(*args, **kw)
+            s.wait_stream(cur)
+            waited = set()
+            for t in _tensors((args, kw), []):
+                src = _Streams.producer.get(t.untyped_storage().data_ptr())
+                if src is not None and src[0] != name and id(src[1]) not in waited:
+                    s.wait_event(src[1])               # only the call that produced this input, not its whole stream
+                    waited.add(id(src[1]))
+                t.record_stream(s)
+            with torch.cuda.stream(s):
+                out = fn(*args, **kw)
+                ev = s.record_event()
+            for t in _tensors(out, []):
+                _Streams.producer[t.untyped_storage().data_ptr()] = (name, ev)
+            _Streams.used.add(name)
+            return out
+        wrapper.__name__ = getattr(fn, "__name__", "wrapped")
+        wrapper.__doc__ = fn.__doc__
+        return wrapper
+    return deco
+
+
 class Var:
     """An activation and its gradient slot."""
     __slots__ = ("v", "g")
@@ -65,9 +162,12 @@ class _Segment(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        cur = torch.cuda.current_stream() if _Streams.used else None
         for o, g in zip(ctx.out_vars, gouts):
             if g is not None and g.dtype != torch.float32:
                 g = g.float()
+            if g is not None and cur is not None:
+                g.record_stream(cur)                  # may have been produced (and be freed) on another stream
             o.g = g
         ctx.tape.backward()
         grads = tuple((v.g if isinstance(v, Var) else None) for v in ctx.in_vars)

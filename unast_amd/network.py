@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import functional as F
 from . import ops
-from .engine import Var, acc, run_segment, FlatStore
+from .engine import Var, acc, run_segment, FlatStore, on_stream
 from .module import (SpeechPrenet, SpeechPostnet, TextPrenet, TextPostnet, PositionalEncoding, TransformerEncoder,
                      TransformerDecoder, RNNEncoder)
 from .spec import state_dict_spec  # noqa: F401  (re-export)
@@ -127,6 +127,7 @@ class TextTransformer(AutoEncoderNet):
     def pe(self):
         return self.pos_emb.pe[0]
 
+    @on_stream("text")
     def encode(self, input_, input_lens, noise_in=False):
         B, T = input_.shape
         lens = lens_i32(input_lens, input_.device)
@@ -138,6 +139,7 @@ class TextTransformer(AutoEncoderNet):
         enc = run_segment(run, None, cx.st.dummy)
         return enc, (None, lens)
 
+    @on_stream("text")
     def decode_sequence(self, tgt, tgt_lens, enc_outputs, masks, teacher_ratio=1):
         B, T = tgt.shape
         Tk = enc_outputs.shape[1]
@@ -193,6 +195,7 @@ class SpeechTransformer(AutoEncoderNet):
     def pe(self):
         return self.pos_emb.pe[0]
 
+    @on_stream("speech")
     def encode(self, input_, input_lens, noise_in=False):
         B, T, M = input_.shape
         lens = lens_i32(input_lens, input_.device)
@@ -204,6 +207,7 @@ class SpeechTransformer(AutoEncoderNet):
         enc = run_segment(run, None, cx.st.dummy)
         return enc, (None, lens)
 
+    @on_stream("speech")
     def decode_sequence(self, tgt, tgt_lens, enc_outputs, masks, teacher_ratio=1):
         B, T, M = tgt.shape
         Tk = enc_outputs.shape[1]
@@ -272,6 +276,7 @@ class LSTMDiscriminator(_Side):
         self.fc2 = nn.Linear(hidden, out)
         self.dropout_p, self.relu_slope = dropout, relu
 
+    @on_stream("disc")
     def forward(self, out, out_len):
         Bd, T, Dm = out.shape
         lens = lens_i32(out_len, out.device)
@@ -302,6 +307,7 @@ class Discriminator(_Side):
         self.fc4 = nn.Linear(hidden, out_classes)
         self.dropout_p, self.relu_slope, self.out_classes = dropout, relu, out_classes
 
+    @on_stream("disc")
     def forward(self, enc_output):
         shape = enc_output.shape
         N, Dm = shape[:-1].numel(), shape[-1]

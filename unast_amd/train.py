@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .engine import Var, run_segment
+from .engine import Var, run_segment, on_stream, side_streams, join_streams
 from .network import TextTransformer, SpeechTransformer, UNAST, Discriminator, LSTMDiscriminator, _as_padded
 from .utils import (PAD_IDX, SOS_IDX, EOS_IDX, lens_i32, specaugment, sent_lens_to_mask, get_teacher_ratio, is_deterministic,
                     set_seed)  # noqa: F401
@@ -105,6 +105,7 @@ def masked_mse(gold_mel, pred_mel, mel_mask):
     raise NotImplementedError("masked_mse is fused into speech_loss (HIP kernel); call speech_loss")
 
 
+@on_stream("text")
 def text_loss(gold_char, text_pred, eos_weight=1.0):
     """src/train.py:105-111.  text_pred is [B, V, T] as in the reference call sites (logits.permute(0, 2, 1))."""
     B, V, T = text_pred.shape
@@ -126,6 +127,7 @@ def text_loss(gold_char, text_pred, eos_weight=1.0):
     return _scalar_segment(fwd, bwd, text_pred)
 
 
+@on_stream("speech")
 def speech_loss(gold_mel, stop_label, pred_mel, post_pred_mel, mel_len, stop_pred, eos_weight=1.0):
     """src/train.py:113-122.  stop_label is implied by mel_len (one-hot at len-1, src/train.py:88) and not read."""
     B, T, M = pred_mel.shape
@@ -158,6 +160,7 @@ def speech_loss(gold_mel, stop_label, pred_mel, post_pred_mel, mel_len, stop_pre
     return _scalar_segment(fwd, bwd, pred_mel, post_pred_mel, stop_pred)
 
 
+@on_stream("disc")
 def discriminator_loss(output, target):
     """src/train.py:147-148."""
     n = output.numel()
@@ -257,6 +260,7 @@ def crossmodel_step(model, batch, args, use_dis_loss=False):
     return t_cm_loss, s_cm_loss
 
 
+@on_stream("disc")
 def discriminator_shuffle_batch(t_hid, t_hid_len, s_hid, s_hid_len, model_type, train_discriminator=False):
     """src/train.py:296-329 for model_type == 'transformer'."""
     if model_type != 'transformer':
@@ -318,6 +322,7 @@ def discriminator_step(model, batch, args):
 #####---- Use these to train on a task -----#####
 def optimizer_step(model, optimizer, args):
     """src/train.py:358-363: clip_grad_norm_ -> optimizer.step() -> zero_grad(set_to_none=True)."""
+    join_streams()                             # gradients were written by up to three streams
     if isinstance(optimizer, FusedAdamW):
         optimizer.step(max_norm=float(args.grad_clip))
         optimizer.zero_grad(set_to_none=True)
@@ -333,14 +338,17 @@ def optimizer_step(model, optimizer, args):
 def train_sp_step(losses, model, batch, step, accum_steps, args):
     """src/train.py:365-390."""
     batch = process_batch(batch)
-    if args.use_discriminator:
-        asr_loss, tts_loss, d_sp_loss = supervised_step(model, batch, args, args.use_discriminator)
-        loss = tts_loss + asr_loss + d_sp_loss
-    else:
-        asr_loss, tts_loss = supervised_step(model, batch, args)
-        loss = tts_loss + asr_loss
-    loss = loss / accum_steps
-    loss.backward()
+    with side_streams():                       # text side / speech side / discriminator on three HIP streams
+        if args.use_discriminator:
+            asr_loss, tts_loss, d_sp_loss = supervised_step(model, batch, args, args.use_discriminator)
+            join_streams()                     # the loss scalars come from three streams; the sums below are torch ops
+            loss = tts_loss + asr_loss + d_sp_loss
+        else:
+            asr_loss, tts_loss = supervised_step(model, batch, args)
+            join_streams()
+            loss = tts_loss + asr_loss
+        loss = loss / accum_steps
+        loss.backward()
     losses['asr_'].append(_log(asr_loss))
     losses['tts_'].append(_log(tts_loss))
     if args.use_discriminator:
@@ -351,14 +359,17 @@ def train_sp_step(losses, model, batch, step, accum_steps, args):
 def train_ae_step(losses, model, batch, step, accum_steps, args):
     """src/train.py:392-416."""
     batch = process_batch(batch)
-    if args.use_discriminator:
-        t_ae_loss, s_ae_loss, d_ae_loss = autoencoder_step(model, batch, args, args.use_discriminator)
-        loss = t_ae_loss + s_ae_loss + d_ae_loss
-    else:
-        t_ae_loss, s_ae_loss = autoencoder_step(model, batch, args)
-        loss = t_ae_loss + s_ae_loss
-    loss = loss / accum_steps
-    loss.backward()
+    with side_streams():
+        if args.use_discriminator:
+            t_ae_loss, s_ae_loss, d_ae_loss = autoencoder_step(model, batch, args, args.use_discriminator)
+            join_streams()
+            loss = t_ae_loss + s_ae_loss + d_ae_loss
+        else:
+            t_ae_loss, s_ae_loss = autoencoder_step(model, batch, args)
+            join_streams()
+            loss = t_ae_loss + s_ae_loss
+        loss = loss / accum_steps
+        loss.backward()
     losses['t_ae'].append(_log(t_ae_loss))
     losses['s_ae'].append(_log(s_ae_loss))
     if args.use_discriminator:
@@ -387,9 +398,11 @@ def train_cm_step(losses, model, batch, step, accum_steps, args):
 def train_discriminator_step(losses, model, batch, step, accum_steps, args, log_out_to_tb=False):
     """src/train.py:446-463."""
     batch = process_batch(batch)
-    d_loss, d_output = discriminator_step(model, batch, args)
-    loss = d_loss / accum_steps
-    loss.backward()
+    with side_streams():
+        d_loss, d_output = discriminator_step(model, batch, args)
+        join_streams()
+        loss = d_loss / accum_steps
+        loss.backward()
     losses['d'].append(_log(d_loss))
     return loss
 
