@@ -55,6 +55,8 @@ class OpTimer:
             self.orig[n] = f
 
             def wrapped(*a, __f=f, __n=n, **k):
+                if torch.cuda.is_current_stream_capturing():      # launches recorded into a HIP graph (generation) are not timed
+                    return __f(*a, **k)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 r = __f(*a, **k)

@@ -166,6 +166,13 @@ int unast_lstm_bwd(const float* dy, const float* dhfinal, const float* whh, cons
 int unast_leaky_dropout(const float* x, const float* dy, float* out, int rows, int D, float slope, float drop_p, unsigned int seed,
                         unsigned int stream_id, hipStream_t stream);
 
+/* Registers a 4-byte counter in device memory that every dropout / noise kernel adds to its stream id (NULL = none).  Launches
+ * replayed from a captured HIP graph carry fixed (seed, stream_id) arguments; the generation loop of infer_sequence
+ * (src/network.py:219-252, 455-481: fresh dropout masks at every decoded position when the model is in training mode)
+ * advances the counter once per position instead.  The counter must read 0 whenever forward/backward pairs run.
+ * Blocking (hipMemcpyToSymbol); call it while no kernel of this library is in flight. */
+int unast_set_rng_epoch(const unsigned int* counter);
+
 /* optimizer_step (src/train.py:358-363): clip_grad_norm_ + torch.optim.AdamW over flat fp32 buffers.
  * split_out (may be NULL; needs n % 4 == 0): the updated parameters once more in the GEMM's pre-split operand format --
  * per 4 consecutive elements one 16-byte chunk [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] of bf16, hi = RNE(x), lo = RNE(x - hi).

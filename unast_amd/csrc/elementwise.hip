@@ -361,3 +361,5 @@ extern "C" int unast_disc_scatter(const float* dout, const int64_t* perm, float*
                        B, Tt, Ts, Tmax, D);
     return unast_check_launch("unast_disc_scatter");
 }
+
+UNAST_DEFINE_RNG_EPOCH_SETTER(elementwise)

@@ -563,3 +563,5 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     }
     return unast_check_launch("unast_gemm");
 }
+
+UNAST_DEFINE_RNG_EPOCH_SETTER(gemm)

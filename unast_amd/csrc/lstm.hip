@@ -215,3 +215,5 @@ extern "C" int unast_leaky_dropout(const float* x, const float* dy, float* out, 
                        drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, stream_id);
     return unast_check_launch("unast_leaky_dropout");
 }
+
+UNAST_DEFINE_RNG_EPOCH_SETTER(lstm)

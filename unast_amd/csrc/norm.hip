@@ -449,3 +449,5 @@ extern "C" int unast_bn_bwd(float* dy_inout, const float* x, const float* mean, 
                        ws, ws + C, dx, rows, C, dgamma, dbeta);
     return unast_check_launch("unast_bn_bwd");
 }
+
+UNAST_DEFINE_RNG_EPOCH_SETTER(norm)

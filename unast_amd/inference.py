@@ -8,6 +8,11 @@ cache, the cross-attention K/V of the memory are projected once per layer, and t
 Positions generated after a sequence has stopped are masked as padded keys exactly as the reference's `dec_mask` does:
 they form a suffix, so the mask is a per-sequence valid length min(i+1, stop_len+1).
 
+One decoded position is ~65 small launches (B rows each), i.e. bound by host launch overhead.  The step therefore keeps its
+position in DEVICE memory (index_select / index_copy_ with a device index, lengths computed on the device), so that it can
+be captured once as a HIP graph and replayed per position (`config.DECODE_GRAPH`); dropout streams of replayed launches are
+varied by the device-side epoch counter of `ops.rng_epoch_counter()`.
+
 Semantics note: with dropout active (model.train() under no_grad, as in cm_text_in / cm_speech_in) the reference draws
 fresh masks for every prefix position at every step; the cached form draws them once per position.  With the RNG sites
 off (parity tests) and in eval mode the two are identical.
@@ -16,7 +21,7 @@ import math
 
 import torch
 
-from . import ops
+from . import config, ops
 from .utils import SOS_IDX, EOS_IDX, PAD_IDX
 
 SYNC_EVERY = 8
@@ -49,13 +54,13 @@ class _LayerStep:
         ops.layernorm_fwd(z, P[pre + "weight"], P[pre + "bias"], y, mean, rstd)
         return y
 
-    def __call__(self, x, pos, lens_self):
+    def __call__(self, x, pos_t, lens_self):
         cx, lp, B, E, H = self.cx, self.lp, self.B, self.E, self.H
         P, p, dev = cx.P, self.p, x.device
         # --- self-attention over the cache (positions 0..pos; stopped sequences keep their frozen valid length)
         qkv = _empty(B, 3 * E, dev=dev)
         ops.linear_fwd(x, P[lp + "self_attn.in_proj_weight"], P[lp + "self_attn.in_proj_bias"], qkv)
-        self.cache[:, pos].copy_(qkv[:, E:])                                    # device-memory plumbing: append K|V
+        self.cache.index_copy_(1, pos_t, qkv[:, E:].unsqueeze(1))               # device-memory plumbing: append K|V at position pos
         kv2d = self.cache.view(B * self.Tcap, 2 * E)
         O = _empty(B, E, dev=dev)
         lse = _empty(B, H, 1, dev=dev)
@@ -80,11 +85,46 @@ class _LayerStep:
         return self._ln(z3, lp + "norm3.")
 
 
-def _posenc_step(cx, x, pe, pos):
+def _posenc_step(cx, x, pe, pos_t):
     """PositionalEncoding for one position: x*sqrt(d) + pe[pos], dropout 0.1 (src/module.py:265-267)."""
     y = torch.empty_like(x)
-    ops.posenc_fwd(x, pe[pos:pos + 1], y, 1, math.sqrt(x.shape[1]), drop_p=cx.p(0.1), seed=cx.seed, stream_id=cx.stream())
+    ops.posenc_fwd(x, pe.index_select(0, pos_t), y, 1, math.sqrt(x.shape[1]), drop_p=cx.p(0.1), seed=cx.seed, stream_id=cx.stream())
     return y
+
+
+def _run_steps(step, pos_t, stop_lens, max_len, reset):
+    """Runs `step()` (one decoded position; advances pos_t on the device) until every sequence has stopped or max_len steps.
+    Returns the number of steps executed.  With config.DECODE_GRAPH the step is captured once and replayed."""
+    def all_stopped():
+        return not bool((stop_lens == max_len).any())                            # the only host read-back of the loop
+    graph = None
+    if config.DECODE_GRAPH and max_len >= 2 * SYNC_EVERY:
+        ctr = ops.rng_epoch_counter()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                                            # warm-up outside capture (lazy initialisations)
+            step()
+        cur.wait_stream(side)
+        reset()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+            ctr.add_(1)                                                          # fresh dropout streams at the next position
+    steps = 0
+    try:
+        for i in range(max_len):
+            if graph is not None:
+                graph.replay()
+            else:
+                step()
+            steps = i + 1
+            if steps % SYNC_EVERY == 0 and all_stopped():
+                break
+    finally:
+        if graph is not None:
+            ops.rng_epoch_counter().zero_()                                      # forward/backward pairs must see epoch 0
+    return steps
 
 
 def _exit_step(stop_lens, max_len):
@@ -109,16 +149,21 @@ def infer_text(m, cx, memory, lens_mem, max_len):
     Emb = P["text_m.prenet.embed.weight"]
     V = P["text_m.postnet.fc1.weight"].shape[0]
     ldl = (V + 3) // 4 * 4
-    steps = 0
-    for i in range(max_len):
-        cur = tokens[:, i].contiguous()
+    pos_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    pt = cx.p(a.t_post_drop)
+
+    def reset():
+        pos_t.zero_()
+        stop_lens.fill_(max_len)
+
+    def step():
+        cur = tokens.index_select(1, pos_t).view(B)
         x = _empty(B, E, dev=dev)
         ops.embed_fwd(cur, Emb, x, 1, drop_p=cx.p(a.t_pre_drop), seed=cx.seed, stream_id=cx.stream())
-        x = _posenc_step(cx, x, m.pe, i)
-        lens_self = torch.clamp(stop_lens + 1, max=i + 1).to(torch.int32)        # dec_mask as a valid-prefix length
+        x = _posenc_step(cx, x, m.pe, pos_t)
+        lens_self = torch.minimum(stop_lens + 1, pos_t + 1).to(torch.int32)      # dec_mask as a valid-prefix length
         for L in layers:
-            x = L(x, i, lens_self)
-        pt = cx.p(a.t_post_drop)
+            x = L(x, pos_t, lens_self)
         if pt > 0:
             xd = torch.empty_like(x)
             ops.leaky_dropout(x, None, xd, 1.0, drop_p=pt, seed=cx.seed, stream_id=cx.stream())
@@ -127,12 +172,12 @@ def infer_text(m, cx, memory, lens_mem, max_len):
         ops.linear_fwd(x, P["text_m.postnet.fc1.weight"], P["text_m.postnet.fc1.bias"], logits[:, :V])
         choice = torch.empty(B, dtype=torch.int64, device=dev)
         ops.argmax_rows(logits, V, choice)
-        tokens[:, i + 1] = choice
+        tokens.index_copy_(1, pos_t + 1, choice.unsqueeze(1))
         newly = (choice == EOS_IDX) & (stop_lens == max_len)                      # loop control on B integers
-        stop_lens = torch.where(newly, torch.full_like(stop_lens, i + 1), stop_lens)
-        steps = i + 1
-        if steps % SYNC_EVERY == 0 and not bool((stop_lens == max_len).any()):
-            break
+        stop_lens.copy_(torch.where(newly, pos_t + 1, stop_lens))
+        pos_t.add_(1)
+
+    steps = _run_steps(step, pos_t, stop_lens, max_len, reset)
     T = min(_exit_step(stop_lens, max_len), steps)
     res = tokens[:, 1:T + 1].contiguous()
     keep = torch.arange(T, device=dev)[None, :] < stop_lens[:, None]
@@ -157,23 +202,28 @@ def infer_speech(m, cx, memory, lens_mem, max_len, speech_prenet_step, postnet_f
     outputs = torch.zeros(B, max_len + 1, M, dtype=torch.float32, device=dev)     # position 0 = all-zero "go" frame
     stops = torch.zeros(B, max_len + 1, dtype=torch.float32, device=dev)
     stop_lens = torch.full((B,), max_len, dtype=torch.int64, device=dev)
-    steps = 0
-    for i in range(max_len):
-        frame = outputs[:, i].contiguous()
+    pos_t = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def reset():
+        pos_t.zero_()
+        stop_lens.fill_(max_len)
+
+    def step():
+        frame = outputs.index_select(1, pos_t).view(B, M)
         x = speech_prenet_step(cx, frame)
-        x = _posenc_step(cx, x, m.pe, i)
-        lens_self = torch.clamp(stop_lens + 1, max=i + 1).to(torch.int32)
+        x = _posenc_step(cx, x, m.pe, pos_t)
+        lens_self = torch.minimum(stop_lens + 1, pos_t + 1).to(torch.int32)
         for L in layers:
-            x = L(x, i, lens_self)
+            x = L(x, pos_t, lens_self)
         head = torch.zeros(B, ldh, dtype=torch.float32, device=dev)
         ops.linear_fwd(x, Wh, bh, head[:, :M + 1])
-        outputs[:, i + 1].copy_(head[:, :M])
-        stops[:, i + 1].copy_(head[:, M])
+        outputs.index_copy_(1, pos_t + 1, head[:, :M].unsqueeze(1))
+        stops.index_copy_(1, pos_t + 1, head[:, M:M + 1])
         stop_mask = (torch.sigmoid(head[:, M]) >= .5) & (stop_lens == max_len)   # loop control (src/network.py:242)
-        stop_lens = torch.where(stop_mask, torch.full_like(stop_lens, i + 1), stop_lens)
-        steps = i + 1
-        if steps % SYNC_EVERY == 0 and not bool((stop_lens == max_len).any()):
-            break
+        stop_lens.copy_(torch.where(stop_mask, pos_t + 1, stop_lens))
+        pos_t.add_(1)
+
+    steps = _run_steps(step, pos_t, stop_lens, max_len, reset)
     T = min(_exit_step(stop_lens, max_len), steps)
     outs = outputs[:, :T + 1].contiguous()
     post = postnet_fn(cx, outs)                                                  # outputs + postnet(outputs), [B,T+1,M]

@@ -332,3 +332,19 @@ def adamw(p, g, m, v, sumsq_scalar, max_norm, lr, beta1, beta2, eps, wd, step, s
 def split_f32(src, dst):
     """dst = src in the GEMM's pre-split operand format (16-B chunks [hi x4 | lo x4] of bf16; same byte offsets)."""
     check(lib().unast_split_f32(_p(src), _p(dst), src.numel(), _stream()), "unast_split_f32")
+
+
+_RNG_EPOCH = {}
+
+
+def rng_epoch_counter():
+    """The device counter mixed into every dropout / noise stream (unast_set_rng_epoch): int32 [1], 0 outside graph replay."""
+    dev = torch.cuda.current_device()
+    c = _RNG_EPOCH.get(dev)
+    if c is None:
+        torch.cuda.synchronize()
+        c = torch.zeros(1, dtype=torch.int32, device="cuda:%d" % dev)
+        torch.cuda.synchronize()
+        check(lib().unast_set_rng_epoch(c.data_ptr()), "unast_set_rng_epoch")
+        _RNG_EPOCH[dev] = c
+    return c
