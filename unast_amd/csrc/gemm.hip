@@ -412,7 +412,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 ? 4 : 2)) void gemm_kernel(c
 //     85 us), an "A-direct" kernel whose waves load their A fragments straight from global memory into registers
 //     (32x128 wave tiles, B alone in LDS; 67 us) and a fully software-pipelined 3-stage version of this kernel (fragments
 //     of tile kt+1 read during the MFMAs of tile kt; 72 us).  Padding the row strides away from powers of two changes
-//     nothing (no channel camping).  What helped: the interior fast path and pre-split weights below (-7 % of GEMM time).
+//     nothing (no channel camping).  Issuing the tile loads through inline asm with hand-placed s_waitcnt vmcnt(N) -- so that
+//     the compiler's vmcnt(0) at the loop top no longer drains the second prefetch set -- kept two sets in flight as designed
+//     (bit-identical results) and changed nothing either (52.5 us): bytes in flight per CU are not the limit.  What helped: the interior fast path and pre-split weights below (-7 % of GEMM time).
 // The remaining lever is fewer operand bytes per FLOP (wider tiles for N >= 512, fusing producer epilogues), not more
 // MFMA overlap.
 
