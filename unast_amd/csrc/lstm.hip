@@ -34,12 +34,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
     const int wave = j >> 6, u = j & 63;
     const int len = lens[b];
-    float w[LH];
+    f32x2 w[LH / 2];                       // row j of W_hh as register pairs: the dot product below runs on v_pk_fma_f32
     const float* wr = whh + dir * whh_dir_stride + (size_t)j * LH;
 #pragma unroll
     for (int k = 0; k < LH; k += 4) {
         float4 v = *reinterpret_cast<const float4*>(wr + k);
-        w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+        w[k / 2] = (f32x2){v.x, v.y}; w[k / 2 + 1] = (f32x2){v.z, v.w};
     }
     const float bias = b_ih[dir * bias_dir_stride + j] + b_hh[dir * bias_dir_stride + j];
     h_lds[wave][u] = 0.f;
@@ -66,13 +66,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
             const int step = s0 + i;
             if (step >= len) break;
             const int t = t0 + step * tstep;
-            float a0 = xc[i] + bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            f32x2 a01 = {xc[i] + bias, 0.f}, a23 = {0.f, 0.f};      // four partial sums as two packed accumulators
 #pragma unroll
             for (int k = 0; k < LH; k += 4) {
                 float4 hv = *reinterpret_cast<const float4*>(&h_lds[wave][k]);
-                a0 = fmaf(w[k], hv.x, a0); a1 = fmaf(w[k + 1], hv.y, a1); a2 = fmaf(w[k + 2], hv.z, a2); a3 = fmaf(w[k + 3], hv.w, a3);
+                a01 = __builtin_elementwise_fma(w[k / 2], (f32x2){hv.x, hv.y}, a01);
+                a23 = __builtin_elementwise_fma(w[k / 2 + 1], (f32x2){hv.z, hv.w}, a23);
             }
-            const float pre = (a0 + a1) + (a2 + a3);
+            const float pre = (a01[0] + a01[1]) + (a23[0] + a23[1]);
             const float act = (wave == 2) ? tanhf_(pre) : sigmoidf_(pre);        // wave-uniform: waves = i,f,g,o
             float* gl = g_lds[i & 1];
             gl[j] = act;
@@ -107,10 +108,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
     const int len = lens[b];
     const int k = j & 63, part = j >> 6;
-    float wt[LH];                       // wt[i] = W_hh[64*part + i][k]
+    f32x2 wt[LH / 2];                   // wt[q] = {W_hh[64*part + 2q][k], W_hh[64*part + 2q+1][k]}: register pairs for v_pk_fma_f32
     const float* wr = whh + dir * whh_dir_stride + (size_t)(part * LH) * LH + k;
 #pragma unroll
-    for (int i = 0; i < LH; ++i) wt[i] = wr[(size_t)i * LH];
+    for (int i = 0; i < LH; i += 2) wt[i / 2] = (f32x2){wr[(size_t)i * LH], wr[(size_t)(i + 1) * LH]};
     float dh = 0.f, dc = 0.f;
     if (dhfinal) dh = dhfinal[(size_t)b * (ndir * LH) + dir * LH + k];
     const int tstep = dir ? 1 : -1;                         // reverse of the forward processing order
@@ -158,14 +159,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
                 float* dgr = dgates + (((size_t)b * T + t) * ndir + dir) * LG;
                 dgr[k] = d_i; dgr[LH + k] = d_f; dgr[2 * LH + k] = d_g; dgr[3 * LH + k] = d_o;
             }
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
             for (int ii = 0; ii < LH; ii += 4) {
                 float4 dv = *reinterpret_cast<const float4*>(&dgw[part * LH + ii]);      // written by this wave just above
-                a0 = fmaf(wt[ii], dv.x, a0); a1 = fmaf(wt[ii + 1], dv.y, a1); a2 = fmaf(wt[ii + 2], dv.z, a2); a3 = fmaf(wt[ii + 3], dv.w, a3);
+                a01 = __builtin_elementwise_fma(wt[ii / 2], (f32x2){dv.x, dv.y}, a01);
+                a23 = __builtin_elementwise_fma(wt[ii / 2 + 1], (f32x2){dv.z, dv.w}, a23);
             }
             float (*pl)[LH] = part_lds[i & 1];
-            pl[part][k] = (a0 + a1) + (a2 + a3);
+            pl[part][k] = (a01[0] + a01[1]) + (a23[0] + a23[1]);
             __syncthreads();
             dh = (pl[0][k] + pl[1][k]) + (pl[2][k] + pl[3][k]);
         }
