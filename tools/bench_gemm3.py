@@ -6,7 +6,7 @@ from bench_gemm import timeit
 D = torch.device("cuda:0")
 tag = os.path.basename(os.environ.get("UNAST_HIP_LIB", "default"))
 res = []
-for (M, N, K) in [(1280, 256, 1024), (25600, 256, 1024), (25600, 256, 256)]:
+for (M, N, K) in [(25600, 256, 1024), (25600, 256, 256), (25600, 1024, 256), (25600, 768, 256)]:
     x = torch.randn(M, K, device=D); W = torch.randn(N, K, device=D); y = torch.empty(M, N, device=D)
     Ws = torch.empty_like(W); ops.split_f32(W, Ws)
     for pre in (0, 1):

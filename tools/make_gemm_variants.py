@@ -40,7 +40,9 @@ def no_barrier(s):
 def no_use(s):      # loads are issued but their data is never waited for (tile content = constants)
     return s.replace("            split4<NSPLIT>(ra[i], hi, lo);\n            const int off = A_KC ?", "            float4 cst = make_float4(1.f, 2.f, 3.f, (float)i); split4<NSPLIT>(p.K < 0 ? ra[i] : cst, hi, lo);\n            const int off = A_KC ?").replace(
         "            if (BSPLIT) {\n                hi[0] = __float_as_uint(rb[i].x);", "            if (p.K > 0) { hi[0] = 1u; hi[1] = 2u; lo[0] = 3u; lo[1] = i; } else if (BSPLIT) {\n                hi[0] = __float_as_uint(rb[i].x);", 1)
-V.update(nobarrier=no_barrier, nouse=no_use, nouse_nobarrier=lambda s: no_barrier(no_use(s)),
+def no_store(s):
+    return s.replace("                *reinterpret_cast<float4*>(cp) = o;", "                if (p.K < 0) *reinterpret_cast<float4*>(cp) = o;")
+V.update(nostore=no_store, nobarrier=no_barrier, nouse=no_use, nouse_nobarrier=lambda s: no_barrier(no_use(s)),
          skeleton=lambda s: no_barrier(no_use(no_lds_read(no_lds_write(few_mfma(s))))),
          nowrite=no_lds_write, fewmfma=few_mfma, nogload=no_gload, noread=no_lds_read,
          nowrite_noread=lambda s: no_lds_read(no_lds_write(s)), nogload_nowrite=lambda s: no_gload(no_lds_write(s)))
