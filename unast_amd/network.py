@@ -418,6 +418,20 @@ class UNAST(_Side):
             return text_pred, s_e_o
         return text_pred
 
+    def tts_and_asr(self, text, text_len, mel, mel_len, mel_aug, ret_enc_hid=False):
+        """`tts(text, text_len, mel, mel_len)` and `asr(text, text_len, mel_aug, mel_len)` of the supervised step
+        (src/train.py:231-259) issued encoder-first: with the text side and the speech side on their own HIP streams the
+        reference's call order (tts, then asr) makes the speech decoder wait for the text encoder while the speech encoder
+        queues behind it, and leaves the text decoder alone at the end.  Same four calls, same arithmetic; only the issue
+        order differs (text encoder | speech encoder, then speech decoder | text decoder)."""
+        t_e_o, t_masks = self.text_m.encode(text, text_len)
+        s_e_o, s_masks = self.speech_m.encode(mel_aug, mel_len)
+        pre_pred, post_pred, stop_pred, stop_lens = self.speech_m.decode_sequence(mel, mel_len, t_e_o, t_masks, teacher_ratio=1)
+        text_pred = self.text_m.decode_sequence(text, text_len, s_e_o, s_masks, teacher_ratio=1)
+        if ret_enc_hid:
+            return (pre_pred, post_pred, stop_pred, stop_lens, t_e_o), (text_pred, s_e_o)
+        return (pre_pred, post_pred, stop_pred, stop_lens), text_pred
+
     def cm_text_in(self, text, text_len, ret_enc_hid=False):
         """src/network.py:103-112: text -> (no grad) TTS inference -> speech encoder -> text decoder."""
         with torch.no_grad():

@@ -222,14 +222,14 @@ def supervised_step(model, batch, args, use_dis_loss=False):
     gold_char, gold_mel, gold_stop = y
     mel_aug = mel if is_deterministic() else specaugment(mel, mel_len)
     if use_dis_loss:
-        pre_pred, post_pred, stop_pred, stop_lens, t_hid = model.tts(text, text_len, mel, mel_len, ret_enc_hid=use_dis_loss)
-        text_pred, s_hid = model.asr(text, text_len, mel_aug, mel_len, ret_enc_hid=use_dis_loss)
+        # model.tts(...) and model.asr(...) as in the reference, issued encoder-first (see UNAST.tts_and_asr)
+        (pre_pred, post_pred, stop_pred, stop_lens, t_hid), (text_pred, s_hid) = model.tts_and_asr(text, text_len, mel, mel_len, mel_aug, ret_enc_hid=True)
         text_pred = text_pred.permute(0, 2, 1)
         d_batch = discriminator_shuffle_batch(t_hid, text_len, s_hid, mel_len, args.model_type)
         d_sp_loss, _ = discriminator_hidden_to_loss(model, d_batch, freeze_discriminator=True)
     else:
-        pre_pred, post_pred, stop_pred, stop_lens = model.tts(text, text_len, mel, mel_len)
-        text_pred = model.asr(text, text_len, mel_aug, mel_len).permute(0, 2, 1)
+        (pre_pred, post_pred, stop_pred, stop_lens), text_pred = model.tts_and_asr(text, text_len, mel, mel_len, mel_aug)
+        text_pred = text_pred.permute(0, 2, 1)
     tts_loss = speech_loss(gold_mel, gold_stop, pre_pred, post_pred, mel_len, stop_pred, args.s_eos_weight)
     asr_loss = text_loss(gold_char, text_pred, args.t_eos_weight)
     if use_dis_loss:
