@@ -218,7 +218,7 @@ def main():
     losses = defaultdict(list)
 
     def one_step(i):
-        train.train_step(losses, model, opt, sched, batches, i, args)
+        train.train_step(losses, model, opt, sched, batches, i, args, defer_d_phase=True)      # as train() does; the timed region ends with a device synchronise
 
     def sync():
         torch.cuda.synchronize(dev)

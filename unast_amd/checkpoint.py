@@ -11,6 +11,8 @@ def save_ckp(epoch, valid_loss, model, optimizer, is_best, checkpoint_path, temp
     """src/utils.py:139-175."""
     if not os.path.exists(checkpoint_path):
         os.makedirs(checkpoint_path)
+    from .engine import join_streams
+    join_streams()                                 # a deferred discriminator phase may still be updating its range
     state = {
         'epoch': epoch + 1,
         'valid_loss_min': valid_loss,

@@ -64,9 +64,20 @@ class side_streams:
 
     def __exit__(self, *exc):
         if self.active:
-            join_streams()
+            if not getattr(self, "leave_open", False):
+                join_streams()
             _Streams.enabled = False
             _Streams.producer.clear()
+
+
+def stream_of(name):
+    """The side stream `name` as a context manager target, or None when side streams are off (callers then stay on the
+    current stream)."""
+    from . import config
+    if not (config.SIDE_STREAMS and torch.cuda.is_available()):
+        return None
+    _Streams.used.add(name)
+    return _side(name)
 
 
 def join_streams():
@@ -314,6 +325,7 @@ class FlatStore:
     def expose_grads(self):
         """Make p.grad views of the flat gradient buffer for every parameter of a touched region (reference
         semantics: parameters that took no part in the backward keep grad None and are skipped by AdamW)."""
+        join_streams()
         for n, p in self.params.items():
             if _region_of(n) in self.touched and p.requires_grad:
                 gv = self.gphys[n]

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .engine import Var, run_segment, on_stream, side_streams, join_streams
+from .engine import Var, run_segment, on_stream, side_streams, join_streams, stream_of
 from .network import TextTransformer, SpeechTransformer, UNAST, Discriminator, LSTMDiscriminator, _as_padded
 from .utils import (PAD_IDX, SOS_IDX, EOS_IDX, lens_i32, specaugment, sent_lens_to_mask, get_teacher_ratio, is_deterministic,
                     set_seed)  # noqa: F401
@@ -320,13 +320,21 @@ def discriminator_step(model, batch, args):
 
 
 #####---- Use these to train on a task -----#####
-def optimizer_step(model, optimizer, args):
+def optimizer_step(model, optimizer, args, defer=False):
     """src/train.py:358-363: clip_grad_norm_ -> optimizer.step() -> zero_grad(set_to_none=True)."""
-    join_streams()                             # gradients were written by up to three streams
     if isinstance(optimizer, FusedAdamW):
+        st = model._store()
+        ds = stream_of("disc") if (defer and st.touched == {"disc"}) else None
+        if ds is not None:                     # D phase: clip + AdamW + zero_grad of the discriminator range on its own stream
+            with torch.cuda.stream(ds):
+                optimizer.step(max_norm=float(args.grad_clip))
+                optimizer.zero_grad(set_to_none=True)
+            return
+        join_streams()                         # gradients were written by up to three streams
         optimizer.step(max_norm=float(args.grad_clip))
         optimizer.zero_grad(set_to_none=True)
         return
+    join_streams()
     model.expose_grads()
     if args.grad_clip > 0.0:
         nn.utils.clip_grad_norm_(model.parameters(), args.grad_clip)
@@ -395,14 +403,25 @@ def train_cm_step(losses, model, batch, step, accum_steps, args):
     return loss
 
 
-def train_discriminator_step(losses, model, batch, step, accum_steps, args, log_out_to_tb=False):
-    """src/train.py:446-463."""
+def train_discriminator_step(losses, model, batch, step, accum_steps, args, log_out_to_tb=False, defer=False):
+    """src/train.py:446-463.  `defer` (used by the training loop, not part of the reference signature): leave the D phase on
+    the discriminator's stream instead of joining it into the caller's stream."""
     batch = process_batch(batch)
-    with side_streams():
+    with side_streams() as ctx:
         d_loss, d_output = discriminator_step(model, batch, args)
-        join_streams()
-        loss = d_loss / accum_steps
-        loss.backward()
+        ds = stream_of("disc") if (ctx.active and defer) else None
+        if ds is None:
+            join_streams()
+            loss = d_loss / accum_steps
+            loss.backward()
+        else:
+            # The whole D phase (forward, backward, and the optimizer step that follows) stays on the discriminator's stream:
+            # with that stream ambient during backward the caller's stream never waits for it, so the next step's generator
+            # forward (which does not read D's weights until its own D call, issued on this same stream) overlaps it.
+            with torch.cuda.stream(ds):
+                loss = d_loss / accum_steps
+                loss.backward()
+            ctx.leave_open = True
     losses['d'].append(_log(d_loss))
     return loss
 
@@ -419,9 +438,12 @@ def unfreeze_model_parameters(model):
         param.requires_grad = True
 
 
-def train_step(losses, model, optimizer, scheduler, batches, step, args):
+def train_step(losses, model, optimizer, scheduler, batches, step, args, defer_d_phase=False):
     """One iteration of the hot loop of train() (src/train.py:602-655).
-    `batches` = dict(unsup=[...ae_steps batches], cm=[...cm_steps], sup=[...sp_steps], disc=[...d_steps])."""
+    `batches` = dict(unsup=[...ae_steps batches], cm=[...cm_steps], sup=[...sp_steps], disc=[...d_steps]).
+    defer_d_phase=True leaves the discriminator phase (backward, clip + AdamW) on its own HIP stream so that the NEXT call's
+    generator forward overlaps it; the caller then has to `join_streams()` (or synchronise the device) before reading
+    parameters, gradients or losses from its own stream.  train() does that at every epoch end."""
     if not model.training:
         model.train()
     if args.use_discriminator:
@@ -437,8 +459,8 @@ def train_step(losses, model, optimizer, scheduler, batches, step, args):
     if args.use_discriminator:
         unfreeze_model_parameters(model.discriminator)
         for si in range(args.d_steps):
-            train_discriminator_step(losses, model, batches["disc"][si], step, args.d_steps, args)
-        optimizer_step(model, optimizer, args)
+            train_discriminator_step(losses, model, batches["disc"][si], step, args.d_steps, args, defer=defer_d_phase)
+        optimizer_step(model, optimizer, args, defer=defer_d_phase)
     if scheduler is not None:
         scheduler.step()
 
@@ -499,10 +521,11 @@ def train(args, batch_getter=None, on_epoch_end=None, valid_dataloader=None):
                 unfreeze_model_parameters(model.discriminator)
                 for si in range(args.d_steps):
                     step = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps + si
-                    train_discriminator_step(losses, model, batch_getter.get_discriminator_batch(), step, args.d_steps, args)
-                optimizer_step(model, optimizer, args)
+                    train_discriminator_step(losses, model, batch_getter.get_discriminator_batch(), step, args.d_steps, args, defer=True)
+                optimizer_step(model, optimizer, args, defer=True)
             if scheduler is not None:
                 scheduler.step()
+        join_streams()                             # the last D phase may still be running on its own stream
         history.append(log_loss_metrics(losses, epoch))
         if not all(v == v and abs(v) < float("inf") for v in history[-1].values()):
             raise RuntimeError("Loss is NaN")               # the reference's check_nan_loss, once per epoch instead of per sub-step
@@ -537,6 +560,7 @@ def evaluate(model, valid_dataloader, step, args, is_test=False):
     import json
     import numpy as np
     from .utils import compute_per, compare_outputs
+    join_streams()
     if is_test:
         os.makedirs(os.path.join(args.out_test_dir, 'mels'), exist_ok=True)
     model.eval()
@@ -639,6 +663,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._m is None or self._m.device != st.flat.device or self._m.numel() != st.total:
             self._m = torch.zeros_like(st.flat)
             self._v = torch.zeros_like(st.flat)
+            self._ss_by_phase = {}
             self._ss = torch.zeros(1, dtype=torch.float64, device=st.flat.device)
 
     @torch.no_grad()
@@ -650,6 +675,11 @@ class FusedAdamW(torch.optim.Optimizer):
             return
         allreduce_grads(st, ranges)
         g = self.param_groups[0]
+        key = tuple(ranges)                    # one norm scalar per phase: the D phase may run on its own stream
+        ss = self._ss_by_phase.get(key)
+        if ss is None:
+            ss = self._ss_by_phase[key] = torch.zeros(1, dtype=torch.float64, device=st.flat.device)
+        self._ss = ss
         self._ss.zero_()
         for a, b in ranges:
             ops.sumsq(st.grad[a:b], self._ss)
