@@ -27,3 +27,8 @@ SIDE_STREAMS = os.environ.get("UNAST_SIDE_STREAMS", "1") != "0"
 # infer_sequence replays ONE captured HIP graph per decoded position (the step is ~65 small launches and otherwise bound by
 # host launch overhead); 0 = launch every kernel from Python.
 DECODE_GRAPH = os.environ.get("UNAST_DECODE_GRAPH", "1") != "0"
+
+# Weight-gradient GEMMs (and their split-K reductions) are issued on a companion stream of the side stream they come from:
+# they are off the backward pass's critical chain (their results are read by the optimizer only) and bandwidth-bound, while
+# the chain they leave behind is attention / dgrad work.  Needs SIDE_STREAMS.
+WGRAD_STREAMS = os.environ.get("UNAST_WGRAD_STREAMS", "1") != "0"

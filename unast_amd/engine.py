@@ -60,14 +60,37 @@ class side_streams:
         if self.active:
             _Streams.enabled = True
             _Streams.producer.clear()
+            if config.WGRAD_STREAMS:
+                ops.WGRAD_SIDE = _wgrad_stream_of_current
         return self
 
     def __exit__(self, *exc):
         if self.active:
+            ops.WGRAD_SIDE = None
             if not getattr(self, "leave_open", False):
                 join_streams()
             _Streams.enabled = False
             _Streams.producer.clear()
+
+
+def _wgrad_stream_of_current():
+    """Companion stream "<name>_w" of the side stream that is current (None on any other stream)."""
+    cur = torch.cuda.current_stream()
+    dev = torch.cuda.current_device()
+    for (d, name), s in _Streams.pool.items():
+        if d == dev and s == cur and not name.endswith("_w"):
+            _Streams.used.add(name + "_w")
+            return _side(name + "_w")
+    return None
+
+
+def join_wgrad_streams():
+    """The current stream waits for the weight-gradient companion streams (before an optimizer step that runs on a side
+    stream itself)."""
+    cur = torch.cuda.current_stream()
+    for name in list(_Streams.used):
+        if name.endswith("_w"):
+            cur.wait_stream(_side(name))
 
 
 def stream_of(name):

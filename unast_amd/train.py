@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .engine import Var, run_segment, on_stream, side_streams, join_streams, stream_of
+from .engine import Var, run_segment, on_stream, side_streams, join_streams, stream_of, join_wgrad_streams
 from .network import TextTransformer, SpeechTransformer, UNAST, Discriminator, LSTMDiscriminator, _as_padded
 from .utils import (PAD_IDX, SOS_IDX, EOS_IDX, lens_i32, specaugment, sent_lens_to_mask, get_teacher_ratio, is_deterministic,
                     set_seed)  # noqa: F401
@@ -327,6 +327,7 @@ def optimizer_step(model, optimizer, args, defer=False):
         ds = stream_of("disc") if (defer and st.touched == {"disc"}) else None
         if ds is not None:                     # D phase: clip + AdamW + zero_grad of the discriminator range on its own stream
             with torch.cuda.stream(ds):
+                join_wgrad_streams()           # its weight gradients were accumulated on the companion stream
                 optimizer.step(max_norm=float(args.grad_clip))
                 optimizer.zero_grad(set_to_none=True)
             return
