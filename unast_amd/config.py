@@ -32,3 +32,6 @@ DECODE_GRAPH = os.environ.get("UNAST_DECODE_GRAPH", "1") != "0"
 # they are off the backward pass's critical chain (their results are read by the optimizer only) and bandwidth-bound, while
 # the chain they leave behind is attention / dgrad work.  Needs SIDE_STREAMS.
 WGRAD_STREAMS = os.environ.get("UNAST_WGRAD_STREAMS", "1") != "0"
+# ... only for weight gradients that reduce over at least this many tokens: the hand-off costs ~15 us of host time per launch,
+# which small (launch-bound) configurations cannot hide (config 2: 22.7 -> 27.7 ms/step without this gate).
+WGRAD_STREAM_MIN_TOKENS = int(os.environ.get("UNAST_WGRAD_MIN_TOKENS", "8192"))

@@ -111,12 +111,12 @@ def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0):
 WGRAD_SIDE = None
 
 
-def _on_wgrad_stream(launch, *operands):
+def _on_wgrad_stream(launch, tokens, *operands):
     """Runs `launch()` on the weight-gradient companion stream of the current stream (if any): that stream first waits for
     everything enqueued so far on the current one (the producers of dy / x), the operands are handed to the caching allocator
     with record_stream, and nobody waits for the result until the optimizer joins the streams.  All weight / bias gradient
     updates of a module come through here, so their read-modify-writes stay ordered on one stream."""
-    w = WGRAD_SIDE() if WGRAD_SIDE is not None else None
+    w = WGRAD_SIDE() if (WGRAD_SIDE is not None and tokens >= config.WGRAD_STREAM_MIN_TOKENS) else None
     if w is None:
         return launch()
     w.wait_stream(torch.cuda.current_stream())
@@ -133,7 +133,7 @@ def linear_wgrad(dy2d, x2d, dW, db=None):
     K = x2d.shape[1]
     sk = _splitk_for(N, K, M)
     _on_wgrad_stream(lambda: gemm(OP_RC, OP_RC, dy2d, dy2d.stride(0), x2d, x2d.stride(0), dW, dW.stride(0), N, K, M, beta=1, splitk=sk,
-                                  rowsum_a=db), dy2d, x2d)
+                                  rowsum_a=db), M, dy2d, x2d)
     return dW
 
 
@@ -160,7 +160,7 @@ def conv_wgrad(dy3d, x3d, dWp, pad_left, db=None):
     Cin = x3d.shape[2]
     sk = _splitk_for(Cout, 5 * Cin, B * T)
     _on_wgrad_stream(lambda: gemm(OP_RC, OP_RC_CONV_WGRAD, dy3d, dy3d.stride(1), x3d, x3d.stride(1), dWp, 5 * Cin, Cout, 5 * Cin, B * T,
-                                  conv=(T, 0, Cin, pad_left), beta=1, splitk=sk, rowsum_a=db), dy3d, x3d)
+                                  conv=(T, 0, Cin, pad_left), beta=1, splitk=sk, rowsum_a=db), B * T, dy3d, x3d)
     return dWp
 
 
