@@ -74,7 +74,10 @@ int unast_layernorm_fwd(const float* z, const float* gamma, const float* beta, f
                         int rows, int C, float eps, hipStream_t stream);
 int unast_layernorm_bwd(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd,
                         float* dz, float* dz_drop, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, int rows, int C,
-                        float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);
+                        float drop_p, unsigned int seed, unsigned int stream_id, int finalize, hipStream_t stream);
+/* finalize = 0 leaves the per-workgroup partial sums of dgamma / dbeta in ws; this entry reduces them into dgamma / dbeta
+ * (accumulating).  The parameter gradients are read by the optimizer only, so the caller may run it on another stream. */
+int unast_layernorm_bwd_finalize(const float* ws, int64_t ws_floats, int rows, int C, float* dgamma, float* dbeta, hipStream_t stream);
 /* floats of `ws` unast_layernorm_bwd needs for (rows, C): per-workgroup column partials, reduced by a second launch
  * (no same-address atomics). */
 int64_t unast_layernorm_bwd_ws_floats(int rows, int C);

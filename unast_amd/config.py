@@ -35,3 +35,5 @@ WGRAD_STREAMS = os.environ.get("UNAST_WGRAD_STREAMS", "1") != "0"
 # ... only for weight gradients that reduce over at least this many tokens: the hand-off costs ~15 us of host time per launch,
 # which small (launch-bound) configurations cannot hide (config 2: 22.7 -> 27.7 ms/step without this gate).
 WGRAD_STREAM_MIN_TOKENS = int(os.environ.get("UNAST_WGRAD_MIN_TOKENS", "8192"))
+# The reduction of LayerNorm's gamma / beta gradient partials is off the backward chain too (same companion stream, same gate).
+LN_FINALIZE_OFFLOAD = os.environ.get("UNAST_LN_FINALIZE_INLINE", "0") != "1"

@@ -361,7 +361,7 @@ extern "C" int64_t unast_layernorm_bwd_ws_floats(int rows, int C) {
 
 extern "C" int unast_layernorm_bwd(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd,
                                    float* dz, float* dz_drop, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, int rows, int C,
-                                   float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream) {
+                                   float drop_p, unsigned int seed, unsigned int stream_id, int finalize, hipStream_t stream) {
     UNAST_REQUIRE(dy && z && gamma && mean && rstd && dz, "unast_layernorm_bwd: null pointer");
     UNAST_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "unast_layernorm_bwd: dgamma/dbeta must both be given or both null");
     UNAST_REQUIRE(rows > 0 && (C & 3) == 0 && C <= 1024, "unast_layernorm_bwd: need C%%4==0, C<=1024 (C=%d)", C);
@@ -371,8 +371,17 @@ extern "C" int unast_layernorm_bwd(const float* dy, const float* z, const float*
     uint32_t th = dz_drop ? drop_threshold(drop_p) : 0u;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, z, gamma, mean, rstd, dz,
                        (th ? dz_drop : (float*)nullptr), (dgamma ? ws : (float*)nullptr), rows, C, rpb, th, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, stream_id);
-    if (dgamma) hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, ws, blocks, C, dgamma, dbeta);
+    if (dgamma && finalize) hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, ws, blocks, C, dgamma, dbeta);
     return unast_check_launch("unast_layernorm_bwd");
+}
+
+extern "C" int unast_layernorm_bwd_finalize(const float* ws, int64_t ws_floats, int rows, int C, float* dgamma, float* dbeta, hipStream_t stream) {
+    UNAST_REQUIRE(ws && dgamma && dbeta && rows > 0 && (C & 3) == 0 && C <= 1024, "unast_layernorm_bwd_finalize: bad arguments");
+    int blocks, rpb;
+    ln_bwd_geometry(rows, &blocks, &rpb);
+    UNAST_REQUIRE(ws_floats >= (int64_t)blocks * 2 * C, "unast_layernorm_bwd_finalize: workspace too small");
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, ws, blocks, C, dgamma, dbeta);
+    return unast_check_launch("unast_layernorm_bwd_finalize");
 }
 
 static int colsum_geometry(int rows, int C, int* blocks, int* rpb) {

@@ -192,7 +192,10 @@ def layernorm_bwd(dy, z, gamma, mean, rstd, dz, dz_drop=None, dgamma=None, dbeta
         ws_n = lib().unast_layernorm_bwd_ws_floats(rows, C)
         ws = torch.empty(ws_n, dtype=torch.float32, device=z.device)
     check(lib().unast_layernorm_bwd(_p(dy), _p(z), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dz_drop), _p(dgamma), _p(dbeta), _p(ws), ws_n,
-                                    rows, C, drop_p, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_layernorm_bwd")
+                                    rows, C, drop_p, seed & 0xFFFFFFFF, stream_id, 0 if dgamma is not None else 1, _stream()), "unast_layernorm_bwd")
+    if dgamma is not None:      # the reduction of the parameter-gradient partials is off the backward chain: companion stream
+        _on_wgrad_stream(lambda: check(lib().unast_layernorm_bwd_finalize(_p(ws), ws_n, rows, C, _p(dgamma), _p(dbeta), _stream()),
+                                       "unast_layernorm_bwd_finalize"), rows if config.LN_FINALIZE_OFFLOAD else 0, ws)
 
 
 def colsum(x2d, out):
