@@ -104,8 +104,9 @@ def stream_of(name):
 
 
 def join_streams():
-    """The current stream waits for everything enqueued on the side streams (before torch ops that read their results,
-    before the optimizer).  Host-side cost only: no device synchronisation."""
+    """The current stream waits for everything enqueued on the side streams and their weight-gradient companions (before
+    torch ops that read their results, at sub-step boundaries, before the optimizer).  Host-side cost only: no device
+    synchronisation.  (Leaving the companions out of the sub-step joins was measured: no gain, 39.0 vs 39.2 ms/step.)"""
     if not _Streams.used:
         return
     cur = torch.cuda.current_stream()
@@ -357,6 +358,7 @@ class FlatStore:
                 p.grad = None
 
     def zero_grad(self):
+        ops.reset_wgrad_choices()
         for r in self.touched:
             a, b = self.regions[r]
             self.grad[a:b].zero_()

@@ -111,12 +111,29 @@ def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0):
 WGRAD_SIDE = None
 
 
-def _on_wgrad_stream(launch, tokens, *operands):
+# Stream choice per gradient buffer for the current optimizer phase (address of dW -> offloaded?).  The first weight-gradient
+# launch into a buffer decides, later ones follow: the token count of a weight's gradient may differ between sub-steps (other
+# batch, other memory length) and may straddle the gate, but its accumulations must all be ordered on ONE stream (defensive: the
+# sub-step joins also wait for the companion streams).  Cleared by FlatStore.zero_grad.
+_WGRAD_CHOICE = {}
+
+
+def reset_wgrad_choices():
+    _WGRAD_CHOICE.clear()
+
+
+def _on_wgrad_stream(launch, tokens, key, *operands):
     """Runs `launch()` on the weight-gradient companion stream of the current stream (if any): that stream first waits for
     everything enqueued so far on the current one (the producers of dy / x), the operands are handed to the caching allocator
     with record_stream, and nobody waits for the result until the optimizer joins the streams.  All weight / bias gradient
     updates of a module come through here, so their read-modify-writes stay ordered on one stream."""
-    w = WGRAD_SIDE() if (WGRAD_SIDE is not None and tokens >= config.WGRAD_STREAM_MIN_TOKENS) else None
+    w = WGRAD_SIDE() if WGRAD_SIDE is not None else None
+    if w is not None:
+        off = _WGRAD_CHOICE.get(key)
+        if off is None:
+            off = _WGRAD_CHOICE[key] = tokens >= config.WGRAD_STREAM_MIN_TOKENS
+        if not off:
+            w = None
     if w is None:
         return launch()
     w.wait_stream(torch.cuda.current_stream())
@@ -133,7 +150,7 @@ def linear_wgrad(dy2d, x2d, dW, db=None):
     K = x2d.shape[1]
     sk = _splitk_for(N, K, M)
     _on_wgrad_stream(lambda: gemm(OP_RC, OP_RC, dy2d, dy2d.stride(0), x2d, x2d.stride(0), dW, dW.stride(0), N, K, M, beta=1, splitk=sk,
-                                  rowsum_a=db), M, dy2d, x2d)
+                                  rowsum_a=db), M, dW.data_ptr(), dy2d, x2d)
     return dW
 
 
@@ -160,7 +177,7 @@ def conv_wgrad(dy3d, x3d, dWp, pad_left, db=None):
     Cin = x3d.shape[2]
     sk = _splitk_for(Cout, 5 * Cin, B * T)
     _on_wgrad_stream(lambda: gemm(OP_RC, OP_RC_CONV_WGRAD, dy3d, dy3d.stride(1), x3d, x3d.stride(1), dWp, 5 * Cin, Cout, 5 * Cin, B * T,
-                                  conv=(T, 0, Cin, pad_left), beta=1, splitk=sk, rowsum_a=db), B * T, dy3d, x3d)
+                                  conv=(T, 0, Cin, pad_left), beta=1, splitk=sk, rowsum_a=db), B * T, dWp.data_ptr(), dy3d, x3d)
     return dWp
 
 
@@ -195,7 +212,7 @@ def layernorm_bwd(dy, z, gamma, mean, rstd, dz, dz_drop=None, dgamma=None, dbeta
                                     rows, C, drop_p, seed & 0xFFFFFFFF, stream_id, 0 if dgamma is not None else 1, _stream()), "unast_layernorm_bwd")
     if dgamma is not None:      # the reduction of the parameter-gradient partials is off the backward chain: companion stream
         _on_wgrad_stream(lambda: check(lib().unast_layernorm_bwd_finalize(_p(ws), ws_n, rows, C, _p(dgamma), _p(dbeta), _stream()),
-                                       "unast_layernorm_bwd_finalize"), rows if config.LN_FINALIZE_OFFLOAD else 0, ws)
+                                       "unast_layernorm_bwd_finalize"), rows if config.LN_FINALIZE_OFFLOAD else 0, dgamma.data_ptr(), ws)
 
 
 def colsum(x2d, out):

@@ -350,7 +350,7 @@ def train_sp_step(losses, model, batch, step, accum_steps, args):
     with side_streams():                       # text side / speech side / discriminator on three HIP streams
         if args.use_discriminator:
             asr_loss, tts_loss, d_sp_loss = supervised_step(model, batch, args, args.use_discriminator)
-            join_streams()                     # the loss scalars come from three streams; the sums below are torch ops
+            join_streams()     # the loss scalars come from three streams; the sums below are torch ops
             loss = tts_loss + asr_loss + d_sp_loss
         else:
             asr_loss, tts_loss = supervised_step(model, batch, args)
