@@ -131,8 +131,8 @@ int unast_scale_inplace(float* a, float alpha, int64_t n, hipStream_t stream);
 /* dst[:, :cols] += src[:, :cols] with independent row strides (autograd's add for padded gradient buffers). */
 int unast_add_strided(float* dst, int ldd, const float* src, int lds, int rows, int cols, hipStream_t stream);
 /* specaugment (src/utils.py:51-75), including its quirk of masking two TIME spans and no frequency columns. */
-int unast_specaugment(const float* mel, const int* lens, float* out, int B, int T, int M, int freq_mask, int time_mask,
-                      unsigned int seed, unsigned int stream_id, hipStream_t stream);
+int unast_specaugment(const float* mel, const int* lens, float* out, float* ws /* B floats of scratch */, int B, int T, int M,
+                      int freq_mask, int time_mask, unsigned int seed, unsigned int stream_id, hipStream_t stream);
 /* discriminator_shuffle_batch (src/train.py:296-329): pad to common T, concat on batch, permute; and its backward. */
 int unast_disc_gather(const float* t_hid, const float* s_hid, const int* t_len, const int* s_len, const int64_t* perm,
                       float* out, int* out_len, int B, int Tt, int Ts, int D, hipStream_t stream);

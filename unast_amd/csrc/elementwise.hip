@@ -168,19 +168,34 @@ __global__ __launch_bounds__(256) void add_strided_kernel(float* __restrict__ ds
 // f ~ U{0..19}, t ~ U{0..99}) are overwritten with that sample's mean over the whole padded [T,M] slab.
 // One block per sample; randomness from the counter RNG (seed, stream, sample).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void specaugment_kernel(const float* __restrict__ mel, const int* __restrict__ lens, float* __restrict__ out,
-                                                          int T, int M, int freq_mask, int time_mask, uint32_t seed, uint32_t stream) {
+// Pass 1: per-sample sum over the padded [T,M] slab (several workgroups per sample, one atomic each).
+__global__ __launch_bounds__(256) void specaugment_sum_kernel(const float* __restrict__ mel, float* __restrict__ sums, int n) {
     __shared__ float red[4];
-    const int b = blockIdx.x;
-    const float* src = mel + (size_t)b * T * M;
-    float* dst = out + (size_t)b * T * M;
-    const int n = T * M;
+    const int b = blockIdx.y;
+    const float* src = mel + (size_t)b * n;
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += src[i];
+    if ((n & 3) == 0) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < (n >> 2); i += gridDim.x * 256) {
+            const float4 v = reinterpret_cast<const float4*>(src)[i];
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) s += src[i];
+    }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+    if (threadIdx.x == 0) atomicAdd(sums + b, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// Pass 2: copy with the two row spans replaced by the sample mean.
+__global__ __launch_bounds__(256) void specaugment_kernel(const float* __restrict__ mel, const int* __restrict__ lens, const float* __restrict__ sums,
+                                                          float* __restrict__ out, int T, int M, int freq_mask, int time_mask, uint32_t seed, uint32_t stream) {
+    const int b = blockIdx.y;
+    const float* src = mel + (size_t)b * T * M;
+    float* dst = out + (size_t)b * T * M;
+    const int n = T * M;
+    const float mean = sums[b] / (float)n;
     const int len = lens[b];
     const uint32_t key = rng_row_key(seed, stream, (uint32_t)b);
     int f = (int)(rng_u32(key, 0) % (uint32_t)freq_mask);
@@ -189,10 +204,19 @@ __global__ __launch_bounds__(256) void specaugment_kernel(const float* __restric
     if (f >= len) f = len - 1 > 0 ? len - 1 : 0;
     const int f0 = (int)(rng_u32(key, 3) % (uint32_t)max(len - f, 1));
     const int t0 = (int)(rng_u32(key, 4) % (uint32_t)max(len - t, 1));
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int row = i / M;
-        const bool masked = (row >= f0 && row < f0 + f) || (row >= t0 && row < t0 + t);
-        dst[i] = masked ? mean : src[i];
+    if ((M & 3) == 0) {
+        const int mq = M >> 2;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < (n >> 2); i += gridDim.x * 256) {
+            const int row = i / mq;
+            const bool masked = (row >= f0 && row < f0 + f) || (row >= t0 && row < t0 + t);
+            reinterpret_cast<float4*>(dst)[i] = masked ? make_float4(mean, mean, mean, mean) : reinterpret_cast<const float4*>(src)[i];
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+            const int row = i / M;
+            const bool masked = (row >= f0 && row < f0 + f) || (row >= t0 && row < t0 + t);
+            dst[i] = masked ? mean : src[i];
+        }
     }
 }
 
@@ -337,10 +361,17 @@ extern "C" int unast_add_strided(float* dst, int ldd, const float* src, int lds,
     return unast_check_launch("unast_add_strided");
 }
 
-extern "C" int unast_specaugment(const float* mel, const int* lens, float* out, int B, int T, int M, int freq_mask, int time_mask,
+extern "C" int unast_specaugment(const float* mel, const int* lens, float* out, float* ws, int B, int T, int M, int freq_mask, int time_mask,
                                  unsigned int seed, unsigned int stream_id, hipStream_t stream) {
-    UNAST_REQUIRE(mel && lens && out && B > 0 && T > 0 && M > 0 && freq_mask > 0 && time_mask > 0, "unast_specaugment: bad arguments");
-    hipLaunchKernelGGL(specaugment_kernel, dim3(B), dim3(256), 0, stream, mel, lens, out, T, M, freq_mask, time_mask, seed, stream_id);
+    UNAST_REQUIRE(mel && lens && out && ws && B > 0 && T > 0 && M > 0 && freq_mask > 0 && time_mask > 0, "unast_specaugment: bad arguments");
+    UNAST_REQUIRE(((((uintptr_t)mel) | ((uintptr_t)out)) & 15) == 0, "unast_specaugment: buffers must be 16-byte aligned");
+    const int n = T * M;
+    int chunks = (n / 4 + 255) / 256;
+    if (chunks > 16) chunks = 16;
+    if (chunks < 1) chunks = 1;
+    hipMemsetAsync(ws, 0, sizeof(float) * B, stream);
+    hipLaunchKernelGGL(specaugment_sum_kernel, dim3(chunks, B), dim3(256), 0, stream, mel, ws, n);
+    hipLaunchKernelGGL(specaugment_kernel, dim3(chunks, B), dim3(256), 0, stream, mel, lens, ws, out, T, M, freq_mask, time_mask, seed, stream_id);
     return unast_check_launch("unast_specaugment");
 }
 

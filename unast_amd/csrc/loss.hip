@@ -32,8 +32,12 @@ __global__ __launch_bounds__(256) void speech_loss_partial_kernel(const float* _
             a2 += (1.f - y) * x + lw * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f));
         }
     }
+    // one set of atomics per WORKGROUP (the three accumulators are same-address atomics: per wave they serialised, 154 us)
+    __shared__ double red[4][3];
     double d0 = wave_sum_d((double)a0), d1 = wave_sum_d((double)a1), d2 = wave_sum_d((double)a2);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(ws + 0, d0); atomicAdd(ws + 1, d1); atomicAdd(ws + 2, d2); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = d0; red[threadIdx.x >> 6][1] = d1; red[threadIdx.x >> 6][2] = d2; }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(ws + threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 __global__ void speech_loss_final_kernel(const double* __restrict__ ws, const int* __restrict__ lens, int B, int T, int M, float* __restrict__ loss) {
@@ -184,7 +188,7 @@ extern "C" int unast_speech_loss_fwd(const float* gold, const float* head, int l
     UNAST_REQUIRE(gold && head && post && lens && ws && loss, "unast_speech_loss_fwd: null pointer");
     UNAST_REQUIRE(B > 0 && T > 0 && (M & 3) == 0 && ldh > M && (ldh & 3) == 0, "unast_speech_loss_fwd: need M%%4==0 and ldh>M, ldh%%4==0");
     hipMemsetAsync(ws, 0, 3 * sizeof(double), stream);
-    hipLaunchKernelGGL(speech_loss_partial_kernel, dim3(ls_grid((size_t)B * T * (M / 4))), dim3(256), 0, stream, gold, head, ldh, post, lens, B, T, M,
+    hipLaunchKernelGGL(speech_loss_partial_kernel, dim3(ls_grid((size_t)B * T * (M / 4), 512)), dim3(256), 0, stream, gold, head, ldh, post, lens, B, T, M,
                        eos_weight, ws);
     hipLaunchKernelGGL(speech_loss_final_kernel, dim3(1), dim3(64), 0, stream, ws, lens, B, T, M, loss);
     return unast_check_launch("unast_speech_loss_fwd");

@@ -292,7 +292,8 @@ def add_strided(dst2d, src2d, cols):
 
 def specaugment(mel, lens_i32, out, seed, stream_id, freq_mask=20, time_mask=100):
     B, T, M = mel.shape
-    check(lib().unast_specaugment(_p(mel), _p(lens_i32), _p(out), B, T, M, freq_mask, time_mask, seed & 0xFFFFFFFF, stream_id, _stream()),
+    ws = torch.empty(B, dtype=torch.float32, device=mel.device)
+    check(lib().unast_specaugment(_p(mel), _p(lens_i32), _p(out), _p(ws), B, T, M, freq_mask, time_mask, seed & 0xFFFFFFFF, stream_id, _stream()),
           "unast_specaugment")
 
 
