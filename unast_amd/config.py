@@ -37,3 +37,6 @@ WGRAD_STREAMS = os.environ.get("UNAST_WGRAD_STREAMS", "1") != "0"
 WGRAD_STREAM_MIN_TOKENS = int(os.environ.get("UNAST_WGRAD_MIN_TOKENS", "8192"))
 # The reduction of LayerNorm's gamma / beta gradient partials is off the backward chain too (same companion stream, same gate).
 LN_FINALIZE_OFFLOAD = os.environ.get("UNAST_LN_FINALIZE_INLINE", "0") != "1"
+
+# Which logical streams share a real HIP stream ("a:x,b:x" puts a and b on the stream named x).  Experiment switch.
+STREAM_GROUPS = dict(kv.split(":") for kv in os.environ.get("UNAST_STREAM_GROUPS", "").split(",") if ":" in kv)

@@ -27,10 +27,17 @@ class _Streams:
     pool = {}            # (device index, name) -> torch.cuda.Stream
     producer = {}        # storage address -> (stream name, event recorded after the producing call); views share the storage
     used = set()
+    trace = None         # list of (stream name, call, start event, end event) when tracing
+
+
+def _stream_group(name):
+    """Logical stream name -> the real stream it runs on (several logical streams may share one)."""
+    from . import config
+    return config.STREAM_GROUPS.get(name, name)
 
 
 def _side(name):
-    key = (torch.cuda.current_device(), name)
+    key = (torch.cuda.current_device(), _stream_group(name))
     s = _Streams.pool.get(key)
     if s is None:
         s = _Streams.pool[key] = torch.cuda.Stream()
@@ -139,7 +146,12 @@ def on_stream(name):
                     waited.add(id(src[1]))
                 t.record_stream(s)
             with torch.cuda.stream(s):
+                if _Streams.trace is not None:          # diagnostic only (tools/stream_timeline.py): event pair around the call
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
                 out = fn(*args, **kw)
+                if _Streams.trace is not None:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                    _Streams.trace.append((name, getattr(fn, "__qualname__", str(fn)), e0, e1))
                 ev = s.record_event()
             for t in _tensors(out, []):
                 _Streams.producer[t.untyped_storage().data_ptr()] = (name, ev)
