@@ -301,15 +301,15 @@ def main():
                     "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["calls"], 1), 0),
                     "launches_per_step": d["calls"] / a.steps, "avg_launch_us": round(d["ms"] * 1e3 / max(d["calls"], 1), 2),
-                    "concurrent_streams": (6 if config.WGRAD_STREAMS else 3) if config.SIDE_STREAMS else 1,
+                    "concurrent_streams": (4 if config.WGRAD_STREAMS else 3) if config.SIDE_STREAMS else 1,
                     "isolated": (None if not iso else (lambda c, ms, by: {"avg_launch_us": round(ms * 1e3 / max(c, 1), 2), "achieved": round(by / (ms * 1e-3) / 1e9, 1),
                                                                           "frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})(
                         sum(v[0] for v in iso.values()), sum(v[1] for v in iso.values()), sum(gemm_bytes(k) * v[0] for k, v in iso.items()))),
                     "mfma_view": {"achieved_tflops": round(ach, 2), "frac_of_2500_dense_bf16": round(ach / PEAK_MFMA_BF16_TFLOPS, 4),
                                   "mfma_issue_tflops": round(ach * config.NSPLIT, 1), "sustained_mfma_peak_measured_tflops": SUSTAINED_MFMA_TFLOPS},
                     "note": "achieved = algorithmic bytes (fp32 A + B + C and epilogue operands, each once; conv inputs once, not per tap) / HIP-event "
-                            "time of these launches inside the timed region (text side, speech side and discriminator run on three HIP streams and their "
-                            "weight gradients on three companion streams, so a launch's duration includes time it shares the chip with kernels of the "
+                            "time of these launches inside the timed region (text side, speech side and discriminator run on three HIP streams and the "
+                            "speech side's weight gradients on a fourth, so a launch's duration includes time it shares the chip with kernels of the "
                             "others; `isolated` = the same launches in two extra single-stream steps after the timed region, comparable with profiles/); traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE per launch from "
                             "profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 passes of this command), null if that file is absent; mfma_view: 2MNK "
                             "FLOPs per contraction, each product costs %d bf16 MFMAs in %s mode; sustained peak = tools/mfma_peak.cpp on this chip" % (config.NSPLIT, a.precision),

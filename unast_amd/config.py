@@ -35,6 +35,10 @@ WGRAD_STREAMS = os.environ.get("UNAST_WGRAD_STREAMS", "1") != "0"
 # ... only for weight gradients that reduce over at least this many tokens: the hand-off costs ~15 us of host time per launch,
 # which small (launch-bound) configurations cannot hide (config 2: 22.7 -> 27.7 ms/step without this gate).
 WGRAD_STREAM_MIN_TOKENS = int(os.environ.get("UNAST_WGRAD_MIN_TOKENS", "8192"))
+# Only the speech side gets a companion: text + speech + discriminator + speech companion = exactly four real streams, one per
+# hardware queue of HIP's default (see unast_amd/__init__.py); the text side's weight gradients are small and the
+# discriminator's run fine on its own stream (same-box A/B: 37.9 ms/step either way, tools/stream_groups_ab.sh).
+WGRAD_COMPANION_OF = set(x for x in os.environ.get("UNAST_WGRAD_COMPANION_OF", "speech").split(",") if x)
 # The reduction of LayerNorm's gamma / beta gradient partials is off the backward chain too (same companion stream, same gate).
 LN_FINALIZE_OFFLOAD = os.environ.get("UNAST_LN_FINALIZE_INLINE", "0") != "1"
 

@@ -84,8 +84,9 @@ def _wgrad_stream_of_current():
     """Companion stream "<name>_w" of the side stream that is current (None on any other stream)."""
     cur = torch.cuda.current_stream()
     dev = torch.cuda.current_device()
+    from . import config
     for (d, name), s in _Streams.pool.items():
-        if d == dev and s == cur and not name.endswith("_w"):
+        if d == dev and s == cur and name in config.WGRAD_COMPANION_OF:
             _Streams.used.add(name + "_w")
             return _side(name + "_w")
     return None
