@@ -140,7 +140,9 @@ def on_stream(name):
                 return fn(*args, **kw)
             s.wait_stream(cur)
             waited = set()
+            inputs = set()
             for t in _tensors((args, kw), []):
+                inputs.add(t.untyped_storage().data_ptr())
                 src = _Streams.producer.get(t.untyped_storage().data_ptr())
                 if src is not None and src[0] != name and id(src[1]) not in waited:
                     s.wait_event(src[1])               # only the call that produced this input, not its whole stream
@@ -155,7 +157,9 @@ def on_stream(name):
                     _Streams.trace.append((name, getattr(fn, "__qualname__", str(fn)), e0, e1))
                 ev = s.record_event()
             for t in _tensors(out, []):
-                _Streams.producer[t.untyped_storage().data_ptr()] = (name, ev)
+                ptr = t.untyped_storage().data_ptr()
+                if ptr not in inputs:                   # an argument handed back (decode_sequence returns tgt_lens) is not a product:
+                    _Streams.producer[ptr] = (name, ev)  # re-tagging it made later users of the batch's lengths wait for this call
             _Streams.used.add(name)
             return out
         wrapper.__name__ = getattr(fn, "__name__", "wrapped")
