@@ -150,11 +150,13 @@ def on_stream(name):
                 t.record_stream(s)
             with torch.cuda.stream(s):
                 if _Streams.trace is not None:          # diagnostic only (tools/stream_timeline.py): event pair around the call
-                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                    import time
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(); h0 = time.perf_counter()
                 out = fn(*args, **kw)
                 if _Streams.trace is not None:
+                    h1 = time.perf_counter()
                     e1 = torch.cuda.Event(enable_timing=True); e1.record()
-                    _Streams.trace.append((name, getattr(fn, "__qualname__", str(fn)), e0, e1))
+                    _Streams.trace.append((name, "%s [host enqueue %.2f ms]" % (getattr(fn, "__qualname__", str(fn)), (h1 - h0) * 1e3), e0, e1))
                 ev = s.record_event()
             for t in _tensors(out, []):
                 ptr = t.untyped_storage().data_ptr()
@@ -209,11 +211,28 @@ class _Segment(torch.autograd.Function):
         in_vars = [Var(t) if isinstance(t, torch.Tensor) and t.is_floating_point() else t for t in inputs]
         outs = run(tape, *in_vars)
         ctx.tape, ctx.in_vars, ctx.out_vars = tape, in_vars, outs
+        ctx.label = getattr(run, "__qualname__", "segment").split(".<locals>")[0]
         res = tuple(o.v for o in outs)
         return res if len(res) > 1 else res[0]
 
     @staticmethod
     def backward(ctx, *gouts):
+        if _Streams.trace is not None:                  # diagnostic only (tools/stream_timeline.py)
+            import time
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            h0 = time.perf_counter()
+            try:
+                return _Segment._backward(ctx, *gouts)
+            finally:
+                h1 = time.perf_counter()
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                cur = torch.cuda.current_stream()
+                nm = next((n for (d, n), st in _Streams.pool.items() if st == cur), "main")
+                _Streams.trace.append((nm, "bwd %s [host enqueue %.2f ms]" % (ctx.label, (h1 - h0) * 1e3), e0, e1))
+        return _Segment._backward(ctx, *gouts)
+
+    @staticmethod
+    def _backward(ctx, *gouts):
         cur = torch.cuda.current_stream() if _Streams.used else None
         for o, g in zip(ctx.out_vars, gouts):
             if g is not None and g.dtype != torch.float32:
