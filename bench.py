@@ -32,6 +32,9 @@ PEAK_MFMA_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 SUSTAINED_MFMA_TFLOPS = 1800.0          # v_mfma_f32_16x16x32_bf16 on random data, all SIMDs busy: 9.2 ns per MFMA per SIMD (tools/mfma_peak.cpp)
 
+# Algorithmic TFLOP of one train step per GPU (full gen+disc step for c3/c5, generator-only for c2).
+STEP_TFLOP = {"c3": 4.875, "c2": 0.510, "c5": 15.940}
+
 WORKLOADS = {
     # name: (B, Tt, Tm, L, use_discriminator)
     "c3": (32, 180, 800, 4, True),      # BASELINE.json configs[2]: the configuration the metric is quoted on
@@ -164,8 +167,8 @@ def cpu_baseline(Tt, Tm, L, use_disc, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default=os.environ.get("UNAST_PREC", "bf16x3"), choices=["bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -335,6 +338,11 @@ def main():
            "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
            "losses_finite": finite, "last_losses": {k: round(v, 5) for k, v in last.items()},
            "roofline": roofline}
+    if a.workload in STEP_TFLOP and not a.cm_steps:
+        tf = STEP_TFLOP[a.workload] * world / (ms * 1e-3)
+        out["whole_step"] = {"algorithmic_tflop_per_step_per_gpu": STEP_TFLOP[a.workload], "achieved_tflops": round(tf, 1),
+                             "frac_of_2500_dense_bf16_per_gpu": round(tf / world / PEAK_MFMA_BF16_TFLOPS, 4),
+                             "note": "SURVEY.md section 8(d) table: multiply-add = 2, backward = 2x forward, causal self-attention at T(T+1)/2"}
     if world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(Tt, Tm, L, use_disc, 150)

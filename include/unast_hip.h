@@ -126,6 +126,18 @@ int unast_add_inplace(float* a, const float* b, int64_t n, hipStream_t stream);
  * first-maximum argmax per row of the logits, and zeroing of generated frames/tokens at t >= lens[b] (int64 lengths). */
 int unast_argmax_rows(const float* x, int ld, int rows, int cols, int64_t* out, hipStream_t stream);
 int unast_mask_by_len(float* x, const int64_t* lens, int B, int T, int D, hipStream_t stream);
+/* Bookkeeping of one autoregressive position with the position in DEVICE memory (graph-replayed decoding step):
+ * begin: lens_self[b] = min(pos+1, stop_lens[b]+1) (the reference's dec_mask, src/network.py:226-231, 461-465), pe_row = pe[pos],
+ *        and the decoder input of this position (cur_tok[b] = tokens[b,pos], or cur_frame[b,:] = frames[b,pos,:]).
+ * end:   prediction -> position pos+1, stop rule (argmax == EOS, src/network.py:470-472; sigmoid(stop) >= .5,
+ *        src/network.py:240-243), then pos += 1 and *epoch += 1 (epoch may be NULL; see unast_set_rng_epoch). */
+int unast_decode_begin(const int64_t* pos, const int64_t* stop_lens, int B, int* lens_self, const float* pe, int D, float* pe_row,
+                       const int64_t* tokens, int ld_tok, int64_t* cur_tok, const float* frames, int ld_frame, int M, float* cur_frame,
+                       hipStream_t stream);
+int unast_decode_end_text(const float* logits, int ld, int V, int B, int64_t* tokens, int ld_tok, int64_t* stop_lens, int64_t max_len, int eos,
+                          int64_t* pos, int* epoch, hipStream_t stream);
+int unast_decode_end_speech(const float* head, int ld, int M, int B, float* outputs, int ld_out, float* stops, int ld_stop, int64_t* stop_lens,
+                            int64_t max_len, int64_t* pos, int* epoch, hipStream_t stream);
 /* a *= alpha: averaging of all-reduced gradients across data-parallel ranks (new vs. the single-device reference). */
 int unast_scale_inplace(float* a, float alpha, int64_t n, hipStream_t stream);
 /* dst[:, :cols] += src[:, :cols] with independent row strides (autograd's add for padded gradient buffers). */

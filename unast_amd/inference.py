@@ -8,7 +8,7 @@ cache, the cross-attention K/V of the memory are projected once per layer, and t
 Positions generated after a sequence has stopped are masked as padded keys exactly as the reference's `dec_mask` does:
 they form a suffix, so the mask is a per-sequence valid length min(i+1, stop_len+1).
 
-One decoded position is ~65 small launches (B rows each), i.e. bound by host launch overhead.  The step therefore keeps its
+One decoded position is ~55 small launches (B rows each), i.e. bound by host launch overhead.  The step therefore keeps its
 position in DEVICE memory (index_select / index_copy_ with a device index, lengths computed on the device), so that it can
 be captured once as a HIP graph and replayed per position (`config.DECODE_GRAPH`); dropout streams of replayed launches are
 varied by the device-side epoch counter of `ops.rng_epoch_counter()`.
@@ -85,16 +85,17 @@ class _LayerStep:
         return self._ln(z3, lp + "norm3.")
 
 
-def _posenc_step(cx, x, pe, pos_t):
+def _posenc_step(cx, x, pe_row):
     """PositionalEncoding for one position: x*sqrt(d) + pe[pos], dropout 0.1 (src/module.py:265-267)."""
     y = torch.empty_like(x)
-    ops.posenc_fwd(x, pe.index_select(0, pos_t), y, 1, math.sqrt(x.shape[1]), drop_p=cx.p(0.1), seed=cx.seed, stream_id=cx.stream())
+    ops.posenc_fwd(x, pe_row, y, 1, math.sqrt(x.shape[1]), drop_p=cx.p(0.1), seed=cx.seed, stream_id=cx.stream())
     return y
 
 
 def _run_steps(step, pos_t, stop_lens, max_len, reset):
-    """Runs `step()` (one decoded position; advances pos_t on the device) until every sequence has stopped or max_len steps.
-    Returns the number of steps executed.  With config.DECODE_GRAPH the step is captured once and replayed."""
+    """Runs `step(epoch)` (one decoded position; advances pos_t -- and the RNG epoch counter if given -- on the device) until
+    every sequence has stopped or max_len steps.  Returns the number of steps executed.  With config.DECODE_GRAPH the step is
+    captured once and replayed."""
     def all_stopped():
         return not bool((stop_lens == max_len).any())                            # the only host read-back of the loop
     graph = None
@@ -104,20 +105,19 @@ def _run_steps(step, pos_t, stop_lens, max_len, reset):
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):                                            # warm-up outside capture (lazy initialisations)
-            step()
+            step(None)
         cur.wait_stream(side)
         reset()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            step()
-            ctr.add_(1)                                                          # fresh dropout streams at the next position
+            step(ctr)                                                            # fresh dropout streams at the next position
     steps = 0
     try:
         for i in range(max_len):
             if graph is not None:
                 graph.replay()
             else:
-                step()
+                step(None)
             steps = i + 1
             if steps % SYNC_EVERY == 0 and all_stopped():
                 break
@@ -151,31 +151,28 @@ def infer_text(m, cx, memory, lens_mem, max_len):
     ldl = (V + 3) // 4 * 4
     pos_t = torch.zeros(1, dtype=torch.int64, device=dev)
     pt = cx.p(a.t_post_drop)
+    logits = torch.zeros(B, ldl, dtype=torch.float32, device=dev)                  # row pitch padded to 16 B; the pad stays zero
 
     def reset():
         pos_t.zero_()
         stop_lens.fill_(max_len)
 
-    def step():
-        cur = tokens.index_select(1, pos_t).view(B)
+    def step(epoch):
+        cur = torch.empty(B, dtype=torch.int64, device=dev)
+        lens_self = torch.empty(B, dtype=torch.int32, device=dev)                # dec_mask as a valid-prefix length
+        pe_row = _empty(1, E, dev=dev)
+        ops.decode_begin(pos_t, stop_lens, lens_self, m.pe, pe_row, tokens=tokens, cur_tok=cur)
         x = _empty(B, E, dev=dev)
         ops.embed_fwd(cur, Emb, x, 1, drop_p=cx.p(a.t_pre_drop), seed=cx.seed, stream_id=cx.stream())
-        x = _posenc_step(cx, x, m.pe, pos_t)
-        lens_self = torch.minimum(stop_lens + 1, pos_t + 1).to(torch.int32)      # dec_mask as a valid-prefix length
+        x = _posenc_step(cx, x, pe_row)
         for L in layers:
             x = L(x, pos_t, lens_self)
         if pt > 0:
             xd = torch.empty_like(x)
             ops.leaky_dropout(x, None, xd, 1.0, drop_p=pt, seed=cx.seed, stream_id=cx.stream())
             x = xd
-        logits = torch.zeros(B, ldl, dtype=torch.float32, device=dev)
         ops.linear_fwd(x, P["text_m.postnet.fc1.weight"], P["text_m.postnet.fc1.bias"], logits[:, :V])
-        choice = torch.empty(B, dtype=torch.int64, device=dev)
-        ops.argmax_rows(logits, V, choice)
-        tokens.index_copy_(1, pos_t + 1, choice.unsqueeze(1))
-        newly = (choice == EOS_IDX) & (stop_lens == max_len)                      # loop control on B integers
-        stop_lens.copy_(torch.where(newly, pos_t + 1, stop_lens))
-        pos_t.add_(1)
+        ops.decode_end_text(logits, V, tokens, stop_lens, max_len, EOS_IDX, pos_t, epoch)   # argmax -> tokens[:, pos+1]; stop rule; pos += 1
 
     steps = _run_steps(step, pos_t, stop_lens, max_len, reset)
     T = min(_exit_step(stop_lens, max_len), steps)
@@ -203,25 +200,23 @@ def infer_speech(m, cx, memory, lens_mem, max_len, speech_prenet_step, postnet_f
     stops = torch.zeros(B, max_len + 1, dtype=torch.float32, device=dev)
     stop_lens = torch.full((B,), max_len, dtype=torch.int64, device=dev)
     pos_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    head = torch.zeros(B, ldh, dtype=torch.float32, device=dev)                   # [mel | stop] rows, pitch padded to 16 B
 
     def reset():
         pos_t.zero_()
         stop_lens.fill_(max_len)
 
-    def step():
-        frame = outputs.index_select(1, pos_t).view(B, M)
+    def step(epoch):
+        frame = _empty(B, M, dev=dev)
+        lens_self = torch.empty(B, dtype=torch.int32, device=dev)
+        pe_row = _empty(1, E, dev=dev)
+        ops.decode_begin(pos_t, stop_lens, lens_self, m.pe, pe_row, frames=outputs, cur_frame=frame)
         x = speech_prenet_step(cx, frame)
-        x = _posenc_step(cx, x, m.pe, pos_t)
-        lens_self = torch.minimum(stop_lens + 1, pos_t + 1).to(torch.int32)
+        x = _posenc_step(cx, x, pe_row)
         for L in layers:
             x = L(x, pos_t, lens_self)
-        head = torch.zeros(B, ldh, dtype=torch.float32, device=dev)
         ops.linear_fwd(x, Wh, bh, head[:, :M + 1])
-        outputs.index_copy_(1, pos_t + 1, head[:, :M].unsqueeze(1))
-        stops.index_copy_(1, pos_t + 1, head[:, M:M + 1])
-        stop_mask = (torch.sigmoid(head[:, M]) >= .5) & (stop_lens == max_len)   # loop control (src/network.py:242)
-        stop_lens.copy_(torch.where(stop_mask, pos_t + 1, stop_lens))
-        pos_t.add_(1)
+        ops.decode_end_speech(head, M, outputs, stops, stop_lens, max_len, pos_t, epoch)   # frame/stop -> pos+1; stop rule (src/network.py:242)
 
     steps = _run_steps(step, pos_t, stop_lens, max_len, reset)
     T = min(_exit_step(stop_lens, max_len), steps)

@@ -280,6 +280,24 @@ def mask_by_len(x3d, lens_i64):
     check(lib().unast_mask_by_len(_p(x3d), _p(lens_i64), B, T, D, _stream()), "unast_mask_by_len")
 
 
+def decode_begin(pos, stop_lens, lens_self, pe, pe_row, tokens=None, cur_tok=None, frames=None, cur_frame=None):
+    B = stop_lens.numel()
+    D = pe.shape[1]
+    M = frames.shape[2] if frames is not None else 0
+    check(lib().unast_decode_begin(_p(pos), _p(stop_lens), B, _p(lens_self), _p(pe), D, _p(pe_row), _p(tokens), tokens.stride(0) if tokens is not None else 0,
+                                   _p(cur_tok), _p(frames), frames.stride(0) if frames is not None else 0, M, _p(cur_frame), _stream()), "unast_decode_begin")
+
+
+def decode_end_text(logits, V, tokens, stop_lens, max_len, eos, pos, epoch):
+    check(lib().unast_decode_end_text(_p(logits), logits.stride(0), V, logits.shape[0], _p(tokens), tokens.stride(0), _p(stop_lens), max_len, eos, _p(pos),
+                                      _p(epoch), _stream()), "unast_decode_end_text")
+
+
+def decode_end_speech(head, M, outputs, stops, stop_lens, max_len, pos, epoch):
+    check(lib().unast_decode_end_speech(_p(head), head.stride(0), M, head.shape[0], _p(outputs), outputs.stride(0), _p(stops), stops.stride(0), _p(stop_lens),
+                                        max_len, _p(pos), _p(epoch), _stream()), "unast_decode_end_speech")
+
+
 def scale_inplace(a, alpha):
     check(lib().unast_scale_inplace(_p(a), float(alpha), a.numel(), _stream()), "unast_scale_inplace")
 
