@@ -218,6 +218,7 @@ def main():
         orig_s, orig_t = model.speech_m.infer_sequence, model.text_m.infer_sequence
         model.speech_m.infer_sequence = lambda memory, masks, max_len=a.cm_max_len: orig_s(memory, masks, max_len)
         model.text_m.infer_sequence = lambda memory, masks, max_len=a.cm_max_len: orig_t(memory, masks, max_len)
+        model.speech_m.infer_max_len = model.text_m.infer_max_len = a.cm_max_len
     losses = defaultdict(list)
 
     def one_step(i):

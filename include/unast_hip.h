@@ -138,6 +138,20 @@ int unast_decode_end_text(const float* logits, int ld, int V, int B, int64_t* to
                           int64_t* pos, int* epoch, hipStream_t stream);
 int unast_decode_end_speech(const float* head, int ld, int M, int B, float* outputs, int ld_out, float* stops, int ld_stop, int64_t* stop_lens,
                             int64_t max_len, int64_t* pos, int* epoch, hipStream_t stream);
+/* Latency-built contraction for the few rows of one decoding position: Y[M,N] = epilogue(X'[M,K] . W[N,K]^T), epilogue as
+ * unast_gemm (bias, act 1 = ReLU, dropout, + R).  X' = X, or LayerNorm(X) over K <= 256 features when ln_gamma/ln_beta are given
+ * (the decoder layers' norm1/2/3, src/module.py:282-291 via nn.TransformerDecoderLayer; xn_out, if not NULL, receives the
+ * normalised rows).  With `cache`, output columns >= split_col go to cache[(m*cache_rows + *pos)*ld_cache + n - split_col] (the
+ * self-attention K|V of this position; *pos is read on the device) and Y receives the columns below split_col only. */
+int unast_decode_linear(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K, int act,
+                        float drop_p, unsigned int seed, unsigned int stream_id, const float* R, int ldr,
+                        const float* ln_gamma, const float* ln_beta, float ln_eps, float* xn_out, int ld_xn,
+                        float* cache, int ld_cache, int cache_rows, int split_col, const int64_t* pos, hipStream_t stream);
+/* One query per (sequence, head) against cached keys/values (head dim 64): O[b, 64h..] = dropout(softmax(scale * q.K^T over the
+ * first lens[b] of the rows_per_seq cached rows of sequence b)) . V  -- the attention of torch's multi_head_attention_forward as
+ * the reference's decoder layers call it at the last position of the prefix (src/network.py:232, 466). */
+int unast_decode_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, int rows_per_seq, const int* lens, float* O, int ldo,
+                      int B, int H, float scale, float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);
 /* a *= alpha: averaging of all-reduced gradients across data-parallel ranks (new vs. the single-device reference). */
 int unast_scale_inplace(float* a, float alpha, int64_t n, hipStream_t stream);
 /* dst[:, :cols] += src[:, :cols] with independent row strides (autograd's add for padded gradient buffers). */

@@ -37,6 +37,7 @@ def build(g):
     orig_s, orig_t = model.speech_m.infer_sequence, model.text_m.infer_sequence
     model.speech_m.infer_sequence = lambda memory, masks, max_len=mel_cap: orig_s(memory, masks, max_len)
     model.text_m.infer_sequence = lambda memory, masks, max_len=text_cap: orig_t(memory, masks, max_len)
+    model.speech_m.infer_max_len, model.text_m.infer_max_len = mel_cap, text_cap        # ... and of the cross-model paths
     model.train()
     return args, model, opt
 
@@ -163,3 +164,20 @@ def test_graph_decoding_draws_fresh_dropout_per_position(golden_dir):
         assert float(d.min()) > 0
     finally:
         utils.set_deterministic(True)
+
+
+def test_lockstep_generation_matches_one_after_the_other(golden_dir):
+    """cm_both_in (the two directions decoded in lock-step, one graph with two branches per position, then the longer one on
+    its own) returns exactly what cm_speech_in followed by cm_text_in return; different caps so that one finishes first."""
+    from unast_amd import train, ops
+    g, batch = load(golden_dir, CASES[0])
+    args, model, opt = build(g)
+    (text, mel, tl, ml), _ = train.process_batch(batch)
+    for caps in ((40, 24), (16, 48)):
+        model.speech_m.infer_max_len, model.text_m.infer_max_len = caps
+        sp = model.cm_speech_in(mel, ml, ret_enc_hid=True)
+        tx = model.cm_text_in(text, tl, ret_enc_hid=True)
+        sp2, tx2 = model.cm_both_in(text, tl, mel, ml, ret_enc_hid=True)
+        for a, b in zip(list(sp) + list(tx), list(sp2) + list(tx2)):
+            assert a.shape == b.shape and torch.equal(a, b)
+        assert int(ops.rng_epoch_counter().item()) == 0

@@ -26,6 +26,7 @@ def build(meta):
     orig_s, orig_t = model.speech_m.infer_sequence, model.text_m.infer_sequence
     model.speech_m.infer_sequence = lambda memory, masks, max_len=mel_cap: orig_s(memory, masks, max_len)
     model.text_m.infer_sequence = lambda memory, masks, max_len=text_cap: orig_t(memory, masks, max_len)
+    model.speech_m.infer_max_len, model.text_m.infer_max_len = mel_cap, text_cap
     return args, model, nb
 
 

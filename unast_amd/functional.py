@@ -574,9 +574,9 @@ def speech_prenet_step(cx, m, frame2d):
     W1, b1 = cx.P["speech_m.prenet.layer.fc1.linear_layer.weight"], cx.P["speech_m.prenet.layer.fc1.linear_layer.bias"]
     W2, b2 = cx.P["speech_m.prenet.layer.fc2.linear_layer.weight"], cx.P["speech_m.prenet.layer.fc2.linear_layer.bias"]
     h1 = _empty(N, W1.shape[0], like=frame2d)
-    ops.linear_fwd(frame2d, W1, b1, h1, act=1, drop_p=cx.p(a.s_pre_drop), seed=cx.seed, stream_id=cx.stream())
+    ops.decode_linear(frame2d, W1, b1, h1, act=1, drop_p=cx.p(a.s_pre_drop), seed=cx.seed, stream_id=cx.stream())
     h2 = _empty(N, W2.shape[0], like=frame2d)
-    ops.linear_fwd(h1, W2, b2, h2, act=1)
+    ops.decode_linear(h1, W2, b2, h2, act=1)
     return h2
 
 

@@ -32,7 +32,9 @@ def _empty(*shape, dev):
 
 
 class _LayerStep:
-    """One decoder layer applied to a single new position per sequence, with cached self-attention K/V."""
+    """One decoder layer applied to a single new position per sequence, with cached self-attention K/V.  Eight launches of the
+    latency-built kernels of csrc/decode.hip: the three LayerNorms are folded into the contraction that consumes them (norm3 into
+    the NEXT layer's first contraction), the K|V of the new position go straight from the in-projection into the cache."""
 
     def __init__(self, cx, lp, mem2d, lens_mem, B, Tk, Tcap, H, drop):
         self.cx, self.lp, self.B, self.Tk, self.Tcap, self.H = cx, lp, B, Tk, Tcap, H
@@ -46,43 +48,60 @@ class _LayerStep:
         ops.linear_fwd(mem2d, Wc[E:], bc[E:], self.memkv)                      # projected once for all steps
         self.cache = torch.zeros(B, Tcap, 2 * E, dtype=torch.float32, device=mem2d.device)
 
-    def _ln(self, z, pre):
-        P = self.cx.P
-        y = torch.empty_like(z)
-        mean = _empty(z.shape[0], dev=z.device)
-        rstd = _empty(z.shape[0], dev=z.device)
-        ops.layernorm_fwd(z, P[pre + "weight"], P[pre + "bias"], y, mean, rstd)
-        return y
+    def norm_out(self):
+        return (self.cx.P[self.lp + "norm3.weight"], self.cx.P[self.lp + "norm3.bias"])
 
-    def __call__(self, x, pos_t, lens_self):
+    def __call__(self, x, ln_in, pos_t, lens_self):
+        """x: the layer input [B,E] -- already normalised if ln_in is None, else the previous layer's pre-norm3 sum with
+        ln_in = (gamma, beta).  Returns this layer's pre-norm3 sum; the consumer applies norm_out()."""
         cx, lp, B, E, H = self.cx, self.lp, self.B, self.E, self.H
         P, p, dev = cx.P, self.p, x.device
         # --- self-attention over the cache (positions 0..pos; stopped sequences keep their frozen valid length)
-        qkv = _empty(B, 3 * E, dev=dev)
-        ops.linear_fwd(x, P[lp + "self_attn.in_proj_weight"], P[lp + "self_attn.in_proj_bias"], qkv)
-        self.cache.index_copy_(1, pos_t, qkv[:, E:].unsqueeze(1))               # device-memory plumbing: append K|V at position pos
+        q = _empty(B, E, dev=dev)
+        if ln_in is not None:
+            xn = _empty(B, E, dev=dev)
+        ops.decode_linear(x, P[lp + "self_attn.in_proj_weight"], P[lp + "self_attn.in_proj_bias"], q, ln=ln_in, xn_out=xn if ln_in is not None else None,
+                          cache=self.cache, split_col=E, pos=pos_t)              # q -> q, K|V -> cache[:, pos]
+        if ln_in is not None:
+            x = xn
         kv2d = self.cache.view(B * self.Tcap, 2 * E)
         O = _empty(B, E, dev=dev)
-        lse = _empty(B, H, 1, dev=dev)
-        ops.attn_fwd(qkv[:, :E], kv2d[:, :E], kv2d[:, E:], O, lse, lens_self, B, H, 1, self.Tcap, False, drop_p=p, seed=cx.seed, stream_id=cx.stream())
-        z = _empty(B, E, dev=dev)
-        ops.linear_fwd(O, P[lp + "self_attn.out_proj.weight"], P[lp + "self_attn.out_proj.bias"], z, drop_p=p, seed=cx.seed, stream_id=cx.stream(), R=x)
-        x1 = self._ln(z, lp + "norm1.")
-        # --- cross-attention over the memory
+        ops.decode_attn(q, kv2d[:, :E], kv2d[:, E:], self.Tcap, lens_self, O, H, drop_p=p, seed=cx.seed, stream_id=cx.stream())
+        z1 = _empty(B, E, dev=dev)
+        ops.decode_linear(O, P[lp + "self_attn.out_proj.weight"], P[lp + "self_attn.out_proj.bias"], z1, drop_p=p, seed=cx.seed, stream_id=cx.stream(), R=x)
+        # --- cross-attention over the memory: q = W_q norm1(z1)
         Wc, bc = P[lp + "multihead_attn.in_proj_weight"], P[lp + "multihead_attn.in_proj_bias"]
-        q = _empty(B, E, dev=dev)
-        ops.linear_fwd(x1, Wc[:E], bc[:E], q)
-        ops.attn_fwd(q, self.memkv[:, :E], self.memkv[:, E:], O, lse, self.lens_mem, B, H, 1, self.Tk, False, drop_p=p, seed=cx.seed, stream_id=cx.stream())
+        q2, x1 = _empty(B, E, dev=dev), _empty(B, E, dev=dev)
+        ops.decode_linear(z1, Wc[:E], bc[:E], q2, ln=(P[lp + "norm1.weight"], P[lp + "norm1.bias"]), xn_out=x1)
+        O2 = _empty(B, E, dev=dev)
+        ops.decode_attn(q2, self.memkv[:, :E], self.memkv[:, E:], self.Tk, self.lens_mem, O2, H, drop_p=p, seed=cx.seed, stream_id=cx.stream())
         z2 = _empty(B, E, dev=dev)
-        ops.linear_fwd(O, P[lp + "multihead_attn.out_proj.weight"], P[lp + "multihead_attn.out_proj.bias"], z2, drop_p=p, seed=cx.seed, stream_id=cx.stream(), R=x1)
-        x2 = self._ln(z2, lp + "norm2.")
-        # --- feed-forward
+        ops.decode_linear(O2, P[lp + "multihead_attn.out_proj.weight"], P[lp + "multihead_attn.out_proj.bias"], z2, drop_p=p, seed=cx.seed, stream_id=cx.stream(), R=x1)
+        # --- feed-forward on norm2(z2)
         W1 = P[lp + "linear1.weight"]
-        h = _empty(B, W1.shape[0], dev=dev)
-        ops.linear_fwd(x2, W1, P[lp + "linear1.bias"], h, act=1, drop_p=p, seed=cx.seed, stream_id=cx.stream())
+        h, x2 = _empty(B, W1.shape[0], dev=dev), _empty(B, E, dev=dev)
+        ops.decode_linear(z2, W1, P[lp + "linear1.bias"], h, act=1, drop_p=p, seed=cx.seed, stream_id=cx.stream(),
+                          ln=(P[lp + "norm2.weight"], P[lp + "norm2.bias"]), xn_out=x2)
         z3 = _empty(B, E, dev=dev)
-        ops.linear_fwd(h, P[lp + "linear2.weight"], P[lp + "linear2.bias"], z3, drop_p=p, seed=cx.seed, stream_id=cx.stream(), R=x2)
-        return self._ln(z3, lp + "norm3.")
+        ops.decode_linear(h, P[lp + "linear2.weight"], P[lp + "linear2.bias"], z3, drop_p=p, seed=cx.seed, stream_id=cx.stream(), R=x2)
+        return z3
+
+
+def _run_layers(layers, x, pos_t, lens_self):
+    """The decoder stack on one position; returns (pre-norm sum of the last layer, that norm's (gamma, beta))."""
+    ln = None
+    for L in layers:
+        x = L(x, ln, pos_t, lens_self)
+        ln = L.norm_out()
+    return x, ln
+
+
+def _layernorm(z, ln):
+    y = torch.empty_like(z)
+    mean = _empty(z.shape[0], dev=z.device)
+    rstd = _empty(z.shape[0], dev=z.device)
+    ops.layernorm_fwd(z, ln[0], ln[1], y, mean, rstd)
+    return y
 
 
 def _posenc_step(cx, x, pe_row):
@@ -127,6 +146,81 @@ def _run_steps(step, pos_t, stop_lens, max_len, reset):
     return steps
 
 
+class _Generation:
+    """One autoregressive generation in flight: `step(epoch)` decodes one position (state in device memory), `reset()` rewinds
+    it, `finish(steps)` turns the buffers into the reference's return values."""
+
+    def __init__(self, step, reset, finish, pos_t, stop_lens, max_len):
+        self.step, self.reset, self.finish = step, reset, finish
+        self.pos_t, self.stop_lens, self.max_len = pos_t, stop_lens, max_len
+        self.steps = 0
+
+    def run(self):
+        self.steps = _run_steps(self.step, self.pos_t, self.stop_lens, self.max_len, self.reset)
+        return self.finish(self.steps)
+
+
+_PAIR_STREAM = {}
+
+
+def run_pair(ga, gb):
+    """Runs two independent generations in lock-step: one captured graph per position with the two steps on two branches
+    (each step is a chain of ~55 dependent, chip-under-filling launches, i.e. bound by dispatch latency, so the two chains
+    overlap almost perfectly).  When one of them is done the other continues with a graph of its own.  The dropout epoch of
+    both is the position, exactly as when they run one after the other.  Returns (ga.finish(..), gb.finish(..))."""
+    if not (config.DECODE_GRAPH and min(ga.max_len, gb.max_len) >= 2 * SYNC_EVERY):
+        return ga.run(), gb.run()
+    ctr = ops.rng_epoch_counter()
+    cur = torch.cuda.current_stream()
+    dev = torch.cuda.current_device()
+    side = _PAIR_STREAM.get(dev)
+    if side is None:
+        side = _PAIR_STREAM[dev] = torch.cuda.Stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):                                                # warm-up outside capture (lazy initialisations)
+        ga.step(None)
+        gb.step(None)
+    cur.wait_stream(side)
+    ga.reset()
+    gb.reset()
+
+    def capture(active):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            if len(active) == 2:
+                cap = torch.cuda.current_stream()
+                side.wait_stream(cap)                                            # fork
+                with torch.cuda.stream(side):
+                    active[1].step(None)
+                active[0].step(None)
+                cap.wait_stream(side)                                            # join: both branches have read this position's epoch
+                ctr.add_(1)
+            else:
+                active[0].step(ctr)
+        return graph
+
+    active = [ga, gb]
+    graph = capture(active)
+    i = 0
+    try:
+        while active:
+            graph.replay()
+            i += 1
+            done = [g for g in active if i >= g.max_len]
+            if i % SYNC_EVERY == 0:
+                live = torch.stack([(g.stop_lens == g.max_len).any() for g in active]).tolist()   # one host read-back
+                done += [g for g, l in zip(active, live) if not l and g not in done]
+            if done:
+                for g in done:
+                    g.steps = i
+                active = [g for g in active if g not in done]
+                if active:
+                    graph = capture(active)
+    finally:
+        ctr.zero_()                                                              # forward/backward pairs must see epoch 0
+    return ga.finish(ga.steps), gb.finish(gb.steps)
+
+
 def _exit_step(stop_lens, max_len):
     """Iteration count at which the reference's loop exits: the step at which the last sequence stopped, else max_len."""
     sl = stop_lens.tolist()
@@ -136,6 +230,12 @@ def _exit_step(stop_lens, max_len):
 @torch.no_grad()
 def infer_text(m, cx, memory, lens_mem, max_len):
     """TextTransformer.infer_sequence (src/network.py:455-481)."""
+    return text_generation(m, cx, memory, lens_mem, max_len).run()
+
+
+@torch.no_grad()
+def text_generation(m, cx, memory, lens_mem, max_len):
+    """The state of TextTransformer.infer_sequence as a _Generation (cross-attention K/V of the memory are projected here)."""
     B, Tk, E = memory.shape
     dev = memory.device
     a = m.args
@@ -165,26 +265,34 @@ def infer_text(m, cx, memory, lens_mem, max_len):
         x = _empty(B, E, dev=dev)
         ops.embed_fwd(cur, Emb, x, 1, drop_p=cx.p(a.t_pre_drop), seed=cx.seed, stream_id=cx.stream())
         x = _posenc_step(cx, x, pe_row)
-        for L in layers:
-            x = L(x, pos_t, lens_self)
-        if pt > 0:
+        z, ln = _run_layers(layers, x, pos_t, lens_self)
+        if pt > 0:                                                               # dropout sits between the last norm and fc1
+            x = _layernorm(z, ln)
             xd = torch.empty_like(x)
             ops.leaky_dropout(x, None, xd, 1.0, drop_p=pt, seed=cx.seed, stream_id=cx.stream())
-            x = xd
-        ops.linear_fwd(x, P["text_m.postnet.fc1.weight"], P["text_m.postnet.fc1.bias"], logits[:, :V])
+            z, ln = xd, None
+        ops.decode_linear(z, P["text_m.postnet.fc1.weight"], P["text_m.postnet.fc1.bias"], logits, ln=ln)
         ops.decode_end_text(logits, V, tokens, stop_lens, max_len, EOS_IDX, pos_t, epoch)   # argmax -> tokens[:, pos+1]; stop rule; pos += 1
 
-    steps = _run_steps(step, pos_t, stop_lens, max_len, reset)
-    T = min(_exit_step(stop_lens, max_len), steps)
-    res = tokens[:, 1:T + 1].contiguous()
-    keep = torch.arange(T, device=dev)[None, :] < stop_lens[:, None]
-    res = res * keep
-    return res, stop_lens
+    def finish(steps):
+        T = min(_exit_step(stop_lens, max_len), steps)
+        res = tokens[:, 1:T + 1].contiguous()
+        keep = torch.arange(T, device=dev)[None, :] < stop_lens[:, None]
+        res = res * keep
+        return res, stop_lens
+
+    return _Generation(step, reset, finish, pos_t, stop_lens, max_len)
 
 
 @torch.no_grad()
 def infer_speech(m, cx, memory, lens_mem, max_len, speech_prenet_step, postnet_fn):
     """SpeechTransformer.infer_sequence (src/network.py:219-252)."""
+    return speech_generation(m, cx, memory, lens_mem, max_len, speech_prenet_step, postnet_fn).run()
+
+
+@torch.no_grad()
+def speech_generation(m, cx, memory, lens_mem, max_len, speech_prenet_step, postnet_fn):
+    """The state of SpeechTransformer.infer_sequence as a _Generation."""
     B, Tk, E = memory.shape
     dev = memory.device
     a = m.args
@@ -213,19 +321,21 @@ def infer_speech(m, cx, memory, lens_mem, max_len, speech_prenet_step, postnet_f
         ops.decode_begin(pos_t, stop_lens, lens_self, m.pe, pe_row, frames=outputs, cur_frame=frame)
         x = speech_prenet_step(cx, frame)
         x = _posenc_step(cx, x, pe_row)
-        for L in layers:
-            x = L(x, pos_t, lens_self)
-        ops.linear_fwd(x, Wh, bh, head[:, :M + 1])
+        z, ln = _run_layers(layers, x, pos_t, lens_self)
+        ops.decode_linear(z, Wh, bh, head, ln=ln)
         ops.decode_end_speech(head, M, outputs, stops, stop_lens, max_len, pos_t, epoch)   # frame/stop -> pos+1; stop rule (src/network.py:242)
 
-    steps = _run_steps(step, pos_t, stop_lens, max_len, reset)
-    T = min(_exit_step(stop_lens, max_len), steps)
-    outs = outputs[:, :T + 1].contiguous()
-    post = postnet_fn(cx, outs)                                                  # outputs + postnet(outputs), [B,T+1,M]
-    pre_res = outs[:, 1:].contiguous()
-    res = post[:, 1:].contiguous()
-    res_stop = stops[:, 1:T + 1].contiguous().unsqueeze(-1)
-    ops.mask_by_len(pre_res, stop_lens)
-    ops.mask_by_len(res, stop_lens)
-    ops.mask_by_len(res_stop, stop_lens)
-    return pre_res, res, res_stop.squeeze(-1), stop_lens
+    @torch.no_grad()
+    def finish(steps):
+        T = min(_exit_step(stop_lens, max_len), steps)
+        outs = outputs[:, :T + 1].contiguous()
+        post = postnet_fn(cx, outs)                                              # outputs + postnet(outputs), [B,T+1,M]
+        pre_res = outs[:, 1:].contiguous()
+        res = post[:, 1:].contiguous()
+        res_stop = stops[:, 1:T + 1].contiguous().unsqueeze(-1)
+        ops.mask_by_len(pre_res, stop_lens)
+        ops.mask_by_len(res, stop_lens)
+        ops.mask_by_len(res_stop, stop_lens)
+        return pre_res, res, res_stop.squeeze(-1), stop_lens
+
+    return _Generation(step, reset, finish, pos_t, stop_lens, max_len)

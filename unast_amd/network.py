@@ -174,8 +174,15 @@ class TextTransformer(AutoEncoderNet):
 
     def infer_sequence(self, memory, masks, max_len=300):
         """src/network.py:455-481 with a K/V cache (unast_amd.inference).  Returns (tokens [B,T], stop_lens [B])."""
-        from .inference import infer_text
-        return infer_text(self, self._ctx(), memory.detach(), masks[1], max_len)
+        return self.generation(memory, masks, max_len).run()
+
+    infer_max_len = 300      # the cap the cross-model paths generate with (= infer_sequence's default)
+
+    def generation(self, memory, masks, max_len=None):
+        """infer_sequence as a resumable unast_amd.inference._Generation (lets UNAST.cm_both_in run two of them in lock-step)."""
+        max_len = max_len or self.infer_max_len
+        from .inference import text_generation
+        return text_generation(self, self._ctx(), memory.detach(), masks[1], max_len)
 
 
 class SpeechTransformer(AutoEncoderNet):
@@ -256,9 +263,15 @@ class SpeechTransformer(AutoEncoderNet):
 
     def infer_sequence(self, memory, masks, max_len=815):
         """src/network.py:219-252 with a K/V cache.  Returns (pre [B,T,M], post [B,T,M], stop [B,T], stop_lens [B])."""
-        from .inference import infer_speech
-        return infer_speech(self, self._ctx(), memory.detach(), masks[1], max_len,
-                            lambda cx, fr: F.speech_prenet_step(cx, self, fr), lambda cx, mel: F.speech_postnet_residual(cx, self, mel))
+        return self.generation(memory, masks, max_len).run()
+
+    infer_max_len = 815
+
+    def generation(self, memory, masks, max_len=None):
+        max_len = max_len or self.infer_max_len
+        from .inference import speech_generation
+        return speech_generation(self, self._ctx(), memory.detach(), masks[1], max_len,
+                                 lambda cx, fr: F.speech_prenet_step(cx, self, fr), lambda cx, mel: F.speech_postnet_residual(cx, self, mel))
 
 
 class LSTMDiscriminator(_Side):
@@ -436,7 +449,7 @@ class UNAST(_Side):
         """src/network.py:103-112: text -> (no grad) TTS inference -> speech encoder -> text decoder."""
         with torch.no_grad():
             t_e_o, t_mask = self.text_m.encode(text, text_len)
-            _, post_pred, _, pred_lens = self.speech_m.infer_sequence(t_e_o, t_mask)
+            _, post_pred, _, pred_lens = self.speech_m.infer_sequence(t_e_o, t_mask, self.speech_m.infer_max_len)
         cm_s_e_o, cm_mask = self.speech_m.encode(post_pred.detach(), pred_lens.detach())
         text_pred = self.text_m.decode_sequence(text, text_len, cm_s_e_o, cm_mask, teacher_ratio=1)
         if ret_enc_hid:
@@ -447,12 +460,30 @@ class UNAST(_Side):
         """src/network.py:114-123: speech -> (no grad) ASR inference -> text encoder -> speech decoder."""
         with torch.no_grad():
             s_e_o, s_mask = self.speech_m.encode(mel, mel_len)
-            text_pred, text_pred_len = self.text_m.infer_sequence(s_e_o, s_mask)
+            text_pred, text_pred_len = self.text_m.infer_sequence(s_e_o, s_mask, self.text_m.infer_max_len)
         cm_t_e_o, cm_t_masks = self.text_m.encode(text_pred.detach(), text_pred_len.detach())
         pre_pred, post_pred, stop_pred, stop_lens = self.speech_m.decode_sequence(mel, mel_len, cm_t_e_o, cm_t_masks, teacher_ratio=1)
         if ret_enc_hid:
             return pre_pred, post_pred, stop_pred, cm_t_e_o, text_pred_len
         return pre_pred, post_pred, stop_pred
+
+    def cm_both_in(self, text, text_len, mel, mel_len, ret_enc_hid=False):
+        """cm_speech_in and cm_text_in of one batch (src/network.py:103-123, called back to back by src/train.py:261-294) with
+        their two generations -- which do not depend on each other -- decoded in lock-step (unast_amd.inference.run_pair).
+        Returns (cm_speech_in's result, cm_text_in's result)."""
+        from .inference import run_pair
+        with torch.no_grad():
+            s_e_o, s_mask = self.speech_m.encode(mel, mel_len)
+            t_e_o, t_mask = self.text_m.encode(text, text_len)
+            (text_pred, text_pred_len), (_, post_pred, _, pred_lens) = run_pair(self.text_m.generation(s_e_o, s_mask),
+                                                                                self.speech_m.generation(t_e_o, t_mask))
+        cm_t_e_o, cm_t_masks = self.text_m.encode(text_pred.detach(), text_pred_len.detach())
+        pre_pred, post_pred_s, stop_pred, stop_lens = self.speech_m.decode_sequence(mel, mel_len, cm_t_e_o, cm_t_masks, teacher_ratio=1)
+        cm_s_e_o, cm_mask = self.speech_m.encode(post_pred.detach(), pred_lens.detach())
+        text_out = self.text_m.decode_sequence(text, text_len, cm_s_e_o, cm_mask, teacher_ratio=1)
+        if ret_enc_hid:
+            return (pre_pred, post_pred_s, stop_pred, cm_t_e_o, text_pred_len), (text_out, cm_s_e_o, pred_lens)
+        return (pre_pred, post_pred_s, stop_pred), text_out
 
     def num_params(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)

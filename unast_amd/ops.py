@@ -280,6 +280,27 @@ def mask_by_len(x3d, lens_i64):
     check(lib().unast_mask_by_len(_p(x3d), _p(lens_i64), B, T, D, _stream()), "unast_mask_by_len")
 
 
+def decode_linear(X, W, bias, Y, act=0, drop_p=0.0, seed=0, stream_id=0, R=None, ln=None, xn_out=None, cache=None, split_col=0, pos=None):
+    """Y = epilogue(X' W^T) for the rows of one decoding position (csrc/decode.hip); ln = (gamma, beta) normalises X first."""
+    M, K = X.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and X.stride(1) == 1 and W.stride(1) == 1
+    g, b = ln if ln is not None else (None, None)
+    check(lib().unast_decode_linear(_p(X), X.stride(0), _p(W), W.stride(0), _p(bias), _p(Y), Y.stride(0) if Y is not None else 0, M, N, K, act,
+                                    float(drop_p), seed, stream_id, _p(R), R.stride(0) if R is not None else 0,
+                                    _p(g), _p(b), 1e-5, _p(xn_out), xn_out.stride(0) if xn_out is not None else 0,
+                                    _p(cache), cache.stride(1) if cache is not None else 0, cache.shape[1] if cache is not None else 0, split_col, _p(pos),
+                                    _stream()), "unast_decode_linear")
+
+
+def decode_attn(Q, K, V, rows_per_seq, lens, O, H, drop_p=0.0, seed=0, stream_id=0):
+    """Single-query attention over cached K/V rows ([B*rows_per_seq, ld] views), head dim 64."""
+    B = Q.shape[0]
+    assert K.stride(0) == V.stride(0) and Q.shape[1] == 64 * H
+    check(lib().unast_decode_attn(_p(Q), Q.stride(0), _p(K), _p(V), K.stride(0), rows_per_seq, _p(lens), _p(O), O.stride(0), B, H, 0.125,
+                                  float(drop_p), seed, stream_id, _stream()), "unast_decode_attn")
+
+
 def decode_begin(pos, stop_lens, lens_self, pe, pe_row, tokens=None, cur_tok=None, frames=None, cur_frame=None):
     B = stop_lens.numel()
     D = pe.shape[1]

@@ -238,21 +238,19 @@ def supervised_step(model, batch, args, use_dis_loss=False):
 
 
 def crossmodel_step(model, batch, args, use_dis_loss=False):
-    """src/train.py:261-294."""
+    """src/train.py:261-294.  The two directions' generations are independent and run in lock-step (UNAST.cm_both_in)."""
     x, y = batch
     text, mel, text_len, mel_len = x
     gold_char, gold_mel, gold_stop = y
+    sp, tx = model.cm_both_in(text, text_len, mel, mel_len, ret_enc_hid=use_dis_loss)
     if use_dis_loss:
-        pre_pred, post_pred, stop_pred, cm_t_hid, cm_t_len = model.cm_speech_in(mel, mel_len, ret_enc_hid=use_dis_loss)
+        pre_pred, post_pred, stop_pred, cm_t_hid, cm_t_len = sp
+        text_pred, cm_s_hid, cm_s_len = tx
     else:
-        pre_pred, post_pred, stop_pred = model.cm_speech_in(mel, mel_len)
+        pre_pred, post_pred, stop_pred = sp
+        text_pred = tx
     s_cm_loss = speech_loss(gold_mel, gold_stop, pre_pred, post_pred, mel_len, stop_pred, args.s_eos_weight)
-    if use_dis_loss:
-        text_pred, cm_s_hid, cm_s_len = model.cm_text_in(text, text_len, ret_enc_hid=use_dis_loss)
-        text_pred = text_pred.permute(0, 2, 1)
-    else:
-        text_pred = model.cm_text_in(text, text_len).permute(0, 2, 1)
-    t_cm_loss = text_loss(gold_char, text_pred, args.t_eos_weight)
+    t_cm_loss = text_loss(gold_char, text_pred.permute(0, 2, 1), args.t_eos_weight)
     if use_dis_loss:
         d_batch = discriminator_shuffle_batch(cm_t_hid, cm_t_len, cm_s_hid, cm_s_len, args.model_type)
         d_cm_loss, _ = discriminator_hidden_to_loss(model, d_batch, freeze_discriminator=True)
