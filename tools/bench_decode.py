@@ -43,6 +43,9 @@ with torch.no_grad():
     ms_t, (tok, tlens) = timed(lambda: model.text_m.infer_sequence(s_enc, s_masks, tc))
     ms_s, (pre, post, st, slens) = timed(lambda: model.speech_m.infer_sequence(t_enc, t_masks, sc))
     ms_p, _ = timed(lambda: run_pair(model.text_m.generation(s_enc, s_masks, tc), model.speech_m.generation(t_enc, t_masks, sc)))
+    # do the two branches of the lock-step graph overlap?  two generations of the same kind, neither stops early
+    ms_tt, _ = timed(lambda: run_pair(model.text_m.generation(s_enc, s_masks, tc), model.text_m.generation(s_enc, s_masks, tc)))
+print("text + text in lock-step: %7.1f ms (one alone: %.1f)" % (ms_tt, ms_t))
 print("text  : %7.1f ms for %d positions (%.0f us/position)" % (ms_t, tok.shape[1], ms_t * 1e3 / max(tok.shape[1], 1)))
 print("speech: %7.1f ms for %d positions (%.0f us/position)" % (ms_s, pre.shape[1], ms_s * 1e3 / max(pre.shape[1], 1)))
 print("stop lengths: text", sorted(set(tlens.tolist())), " speech", sorted(set(slens.tolist())))

@@ -11,8 +11,9 @@
 //     fusions that remove launches from the chain: LayerNorm of the INPUT rows (every workgroup recomputes the 32 row statistics
 //     from L2 -- 32 KB -- and workgroup 0 writes the normalised rows out for later residual use), and appending the output
 //     columns >= split_col to a K/V cache row selected by a position kept in device memory.
-//   * decode_attn: one workgroup per (sequence, head); scores, softmax and P.V in fp32 on the vector ALUs (2 x 64 x Tk FMAs:
-//     nothing), K and V each read once with 16 lanes per 256-byte row; bound by how fast one CU streams its 2 x Tk x 256 B.
+//   * decode_attn: one 16-wave workgroup per (sequence, head); scores, softmax and P.V in fp32 on the vector ALUs (2 x 64 x Tk
+//     FMAs: nothing), K and V each read once with 16 lanes per 256-byte row and no synchronisation inside the key loop; bound
+//     by how fast one CU streams its 2 x Tk x 256 B.
 #include "common.h"
 
 struct DecLinParams {
@@ -198,67 +199,83 @@ struct DecAttnParams {
     uint32_t drop_thresh; float drop_scale; uint32_t seed, stream;
 };
 
-__global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnParams p) {
-    extern __shared__ float sc[];                       // rows_per_seq scores / probabilities
-    __shared__ float wred[4];
-    __shared__ float ored[4][64];
+// 16 waves per (sequence, head).  A group of 16 lanes owns the keys slot, slot+64, ... (slot = 4*wave + lane/16) and keeps a
+// private online-softmax state (running max, sum, 4 of the 64 output features per lane), so the key loop has no workgroup-wide
+// synchronisation and the K and V rows of 4 keys per group (8 x 16 B per lane, 128 KB per workgroup) are in flight at once;
+// the 64 groups' states are merged once at the end (shuffles inside a wave, LDS across waves).
+#define DA_THREADS 1024
+#define DA_SLOTS (DA_THREADS / 16)
+__global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(const DecAttnParams p) {
+    __shared__ float wm[DA_THREADS / 64], wl[DA_THREADS / 64];
+    __shared__ float wacc[DA_THREADS / 64][64];
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
     const int t = threadIdx.x, w = t >> 6, lane = t & 63, sg = lane >> 4, c = lane & 15;
     int n = p.lens[b];
     n = n < 0 ? 0 : (n > p.rows_per_seq ? p.rows_per_seq : n);
-    const float4 q4 = *reinterpret_cast<const float4*>(p.Q + (size_t)b * p.ldq + h * 64 + c * 4);
+    float4 q4 = *reinterpret_cast<const float4*>(p.Q + (size_t)b * p.ldq + h * 64 + c * 4);
+    q4.x *= p.scale; q4.y *= p.scale; q4.z *= p.scale; q4.w *= p.scale;         // a power of two for head dim 64: exact
     const float* kb = p.K + (size_t)b * p.rows_per_seq * p.ldkv + h * 64 + c * 4;
     const float* vb = p.V + (size_t)b * p.rows_per_seq * p.ldkv + h * 64 + c * 4;
-
-    // ---- scores: a 16-lane group per key (4 keys per wave instruction, 16 per workgroup round)
-    float mx = -INFINITY;
-#pragma unroll 4
-    for (int key = w * 4 + sg; key < n; key += 16) {
-        const float4 k4 = *reinterpret_cast<const float4*>(kb + (size_t)key * p.ldkv);
-        float s = (q4.x * k4.x + q4.y * k4.y) + (q4.z * k4.z + q4.w * k4.w);
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        s *= p.scale;
-        if (c == 0) sc[key] = s;
-        mx = fmaxf(mx, s);
-    }
-    mx = wave_max(mx);
-    if (lane == 0) wred[w] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-    __syncthreads();
-
-    // ---- softmax numerators (dropout applies to the normalised probabilities: the sum is taken before it)
     const uint32_t rkey = p.drop_thresh ? rng_row_key(p.seed, p.stream, (uint32_t)(b * p.H + h)) : 0u;
-    float sum = 0.f;
-    for (int key = t; key < n; key += 256) {
-        const float e = __expf(sc[key] - mx);
-        sum += e;
-        sc[key] = (!p.drop_thresh || rng_keep(rkey, (uint32_t)key, p.drop_thresh)) ? e * p.drop_scale : 0.f;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) wred[w] = sum;
-    __syncthreads();
-    sum = (wred[0] + wred[1]) + (wred[2] + wred[3]);
 
-    // ---- P . V: same key -> lane-group mapping; lane keeps 4 of the 64 output features
+    float m = -INFINITY, l = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int key = w * 4 + sg; key < n; key += 16) {
-        const float4 v4 = *reinterpret_cast<const float4*>(vb + (size_t)key * p.ldkv);
-        const float pk = sc[key];
-        acc.x += pk * v4.x; acc.y += pk * v4.y; acc.z += pk * v4.z; acc.w += pk * v4.w;
+    for (int k0 = w * 4 + sg; k0 < n; k0 += 4 * DA_SLOTS) {
+        float4 k4[4], v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = k0 + u * DA_SLOTS;
+            const size_t off = (size_t)(key < n ? key : k0) * p.ldkv;
+            k4[u] = *reinterpret_cast<const float4*>(kb + off);
+            v4[u] = *reinterpret_cast<const float4*>(vb + off);
+        }
+        float sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float s = (q4.x * k4[u].x + q4.y * k4[u].y) + (q4.z * k4[u].z + q4.w * k4[u].w);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            sc[u] = (k0 + u * DA_SLOTS < n) ? s : -INFINITY;
+        }
+        const float mn = fmaxf(fmaxf(m, sc[0]), fmaxf(fmaxf(sc[1], sc[2]), sc[3]));      // finite: key k0 is valid
+        const float corr = __expf(m - mn);
+        l *= corr; acc.x *= corr; acc.y *= corr; acc.z *= corr; acc.w *= corr;
+        m = mn;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float e = __expf(sc[u] - mn);
+            l += e;                                         // dropout applies to the normalised probabilities: the sum is taken before it
+            const float pk = (!p.drop_thresh || rng_keep(rkey, (uint32_t)(k0 + u * DA_SLOTS), p.drop_thresh)) ? e * p.drop_scale : 0.f;
+            acc.x += pk * v4[u].x; acc.y += pk * v4[u].y; acc.z += pk * v4[u].z; acc.w += pk * v4[u].w;
+        }
     }
+    // ---- merge the 4 groups of the wave
+    float mw = fmaxf(m, __shfl_xor(m, 16, 64));
+    mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+    const float f = (m == -INFINITY) ? 0.f : __expf(m - mw);                      // a group without keys contributes nothing
+    l *= f; acc.x *= f; acc.y *= f; acc.z *= f; acc.w *= f;
 #pragma unroll
     for (int o = 16; o < 64; o <<= 1) {
+        l += __shfl_xor(l, o, 64);
         acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
         acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
     }
-    if (sg == 0) *reinterpret_cast<float4*>(&ored[w][c * 4]) = acc;
+    if (sg == 0) *reinterpret_cast<float4*>(&wacc[w][c * 4]) = acc;
+    if (lane == 0) { wm[w] = mw; wl[w] = l; }
     __syncthreads();
+    // ---- ... and the 16 waves
     if (t < 64) {
-        const float o = (ored[0][t] + ored[1][t]) + (ored[2][t] + ored[3][t]);
-        p.O[(size_t)b * p.ldo + h * 64 + t] = n > 0 ? o / sum : 0.f;
+        float M = wm[0];
+#pragma unroll
+        for (int i = 1; i < DA_THREADS / 64; ++i) M = fmaxf(M, wm[i]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int i = 0; i < DA_THREADS / 64; ++i) {
+            const float fi = (wm[i] == -INFINITY) ? 0.f : __expf(wm[i] - M);
+            L += wl[i] * fi;
+            o += wacc[i][t] * fi;
+        }
+        p.O[(size_t)b * p.ldo + h * 64 + t] = n > 0 ? o / L : 0.f;
     }
 }
 
@@ -266,11 +283,10 @@ extern "C" int unast_decode_attn(const float* Q, int ldq, const float* K, const 
                                  int B, int H, float scale, float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream) {
     UNAST_REQUIRE(Q && K && V && lens && O && B > 0 && H > 0 && rows_per_seq > 0, "unast_decode_attn: bad arguments");
     UNAST_REQUIRE((ldq & 3) == 0 && (ldkv & 3) == 0 && ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V)) & 15) == 0, "unast_decode_attn: rows must be 16-byte aligned");
-    UNAST_REQUIRE(rows_per_seq <= 15360, "unast_decode_attn: at most 15360 cached positions per sequence (scores live in LDS)");
     DecAttnParams p;
     p.Q = Q; p.ldq = ldq; p.K = K; p.V = V; p.ldkv = ldkv; p.rows_per_seq = rows_per_seq; p.lens = lens; p.O = O; p.ldo = ldo; p.H = H; p.scale = scale;
     p.drop_thresh = drop_threshold(drop_p); p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.seed = seed; p.stream = stream_id;
-    hipLaunchKernelGGL(decode_attn_kernel, dim3(B * H), dim3(256), (size_t)rows_per_seq * sizeof(float), stream, p);
+    hipLaunchKernelGGL(decode_attn_kernel, dim3(B * H), dim3(DA_THREADS), 0, stream, p);
     return unast_check_launch("unast_decode_attn");
 }
 
