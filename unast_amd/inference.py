@@ -111,6 +111,30 @@ def _posenc_step(cx, x, pe_row):
     return y
 
 
+_CAPTURE_STREAM = {}
+
+
+def _capture(fn, pool=None):
+    """Captures fn() into a HIP graph on a dedicated stream.  torch.cuda.graph() is not used: on entry it collects garbage and
+    EMPTIES the caching allocator (12 ms per capture here, and the train step that follows has to hipMalloc its whole working
+    set again)."""
+    dev = torch.cuda.current_device()
+    cs = _CAPTURE_STREAM.get(dev)
+    if cs is None:
+        cs = _CAPTURE_STREAM[dev] = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    graph = torch.cuda.CUDAGraph()
+    cs.wait_stream(cur)
+    with torch.cuda.stream(cs):
+        graph.capture_begin(**({"pool": pool} if pool is not None else {}))
+        try:
+            fn()
+        finally:
+            graph.capture_end()
+    cur.wait_stream(cs)
+    return graph
+
+
 def _run_steps(step, pos_t, stop_lens, max_len, reset):
     """Runs `step(epoch)` (one decoded position; advances pos_t -- and the RNG epoch counter if given -- on the device) until
     every sequence has stopped or max_len steps.  Returns the number of steps executed.  With config.DECODE_GRAPH the step is
@@ -127,9 +151,7 @@ def _run_steps(step, pos_t, stop_lens, max_len, reset):
             step(None)
         cur.wait_stream(side)
         reset()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step(ctr)                                                            # fresh dropout streams at the next position
+        graph = _capture(lambda: step(ctr))                                      # ctr: fresh dropout streams at the next position
     steps = 0
     try:
         for i in range(max_len):
@@ -185,19 +207,15 @@ def run_pair(ga, gb):
     gb.reset()
 
     def capture(active):
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            if len(active) == 2:
-                cap = torch.cuda.current_stream()
-                side.wait_stream(cap)                                            # fork
-                with torch.cuda.stream(side):
-                    active[1].step(None)
-                active[0].step(None)
-                cap.wait_stream(side)                                            # join: both branches have read this position's epoch
-                ctr.add_(1)
-            else:
-                active[0].step(ctr)
-        return graph
+        def both():
+            cap = torch.cuda.current_stream()
+            side.wait_stream(cap)                                                # fork
+            with torch.cuda.stream(side):
+                active[1].step(None)
+            active[0].step(None)
+            cap.wait_stream(side)                                                # join: both branches have read this position's epoch
+            ctr.add_(1)
+        return _capture(both if len(active) == 2 else (lambda: active[0].step(ctr)))
 
     active = [ga, gb]
     graph = capture(active)
