@@ -8,10 +8,12 @@ cache, the cross-attention K/V of the memory are projected once per layer, and t
 Positions generated after a sequence has stopped are masked as padded keys exactly as the reference's `dec_mask` does:
 they form a suffix, so the mask is a per-sequence valid length min(i+1, stop_len+1).
 
-One decoded position is ~55 small launches (B rows each), i.e. bound by host launch overhead.  The step therefore keeps its
-position in DEVICE memory (index_select / index_copy_ with a device index, lengths computed on the device), so that it can
-be captured once as a HIP graph and replayed per position (`config.DECODE_GRAPH`); dropout streams of replayed launches are
-varied by the device-side epoch counter of `ops.rng_epoch_counter()`.
+One decoded position is ~39 small launches on B rows each (csrc/decode.hip: contractions and single-query attention built for
+latency), i.e. bound by launch overhead.  The step therefore keeps its position in DEVICE memory (decode_begin / decode_end_*
+read and advance it, the in-projection appends K|V at it), so that it can be captured once as a HIP graph and replayed per
+position (`config.DECODE_GRAPH`); dropout streams of replayed launches are varied by the device-side epoch counter of
+`ops.rng_epoch_counter()`.  Two generations that do not depend on each other (the two directions of a cross-model step) are
+decoded in lock-step from one graph with two branches (`run_pair`).
 
 Semantics note: with dropout active (model.train() under no_grad, as in cm_text_in / cm_speech_in) the reference draws
 fresh masks for every prefix position at every step; the cached form draws them once per position.  With the RNG sites
@@ -187,7 +189,7 @@ _PAIR_STREAM = {}
 
 def run_pair(ga, gb):
     """Runs two independent generations in lock-step: one captured graph per position with the two steps on two branches
-    (each step is a chain of ~55 dependent, chip-under-filling launches, i.e. bound by dispatch latency, so the two chains
+    (each step is a chain of ~39 dependent, chip-under-filling launches, i.e. bound by dispatch latency, so the two chains
     overlap almost perfectly).  When one of them is done the other continues with a graph of its own.  The dropout epoch of
     both is the position, exactly as when they run one after the other.  Returns (ga.finish(..), gb.finish(..))."""
     if not (config.DECODE_GRAPH and min(ga.max_len, gb.max_len) >= 2 * SYNC_EVERY):
