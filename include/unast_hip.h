@@ -126,32 +126,40 @@ int unast_add_inplace(float* a, const float* b, int64_t n, hipStream_t stream);
  * first-maximum argmax per row of the logits, and zeroing of generated frames/tokens at t >= lens[b] (int64 lengths). */
 int unast_argmax_rows(const float* x, int ld, int rows, int cols, int64_t* out, hipStream_t stream);
 int unast_mask_by_len(float* x, const int64_t* lens, int B, int T, int D, hipStream_t stream);
-/* Bookkeeping of one autoregressive position with the position in DEVICE memory (graph-replayed decoding step):
- * begin: lens_self[b] = min(pos+1, stop_lens[b]+1) (the reference's dec_mask, src/network.py:226-231, 461-465), pe_row = pe[pos],
- *        and the decoder input of this position (cur_tok[b] = tokens[b,pos], or cur_frame[b,:] = frames[b,pos,:]).
- * end:   prediction -> position pos+1, stop rule (argmax == EOS, src/network.py:470-472; sigmoid(stop) >= .5,
- *        src/network.py:240-243), then pos += 1 and *epoch += 1 (epoch may be NULL; see unast_set_rng_epoch). */
-int unast_decode_begin(const int64_t* pos, const int64_t* stop_lens, int B, int* lens_self, const float* pe, int D, float* pe_row,
-                       const int64_t* tokens, int ld_tok, int64_t* cur_tok, const float* frames, int ld_frame, int M, float* cur_frame,
-                       hipStream_t stream);
+/* ---- one autoregressive decoding position (csrc/decode.hip; reference: infer_sequence, src/network.py:219-252, 455-481) -------
+ * The position is kept in DEVICE memory (*pos), so a position's launches can be replayed from a captured graph.
+ *
+ * unast_decode_linear: latency-built contraction for the few rows of one position: Y[M,N] = epilogue(X'[M,K] . W[N,K]^T), epilogue
+ * as unast_gemm (bias, act 1 = ReLU, dropout, + R).  X rows start at X + *pos * x_pos_stride (x_pos_stride 0: plain X).
+ * prologue selects X' (for 1..4: K <= 256; xn_out, if not NULL, receives X'):
+ *   0  X
+ *   1  LayerNorm(X)                          (the decoder layers' norm1/2/3, nn.TransformerDecoderLayer as built by src/module.py:282-291)
+ *   2  dropout(LayerNorm(X), pro_drop2)      (text postnet: dropout before fc1, src/module.py TextPostnet)
+ *   3  dropout(dropout(emb[tokens[m, *pos]], pro_drop1) * pro_scale + pe[*pos], pro_drop2)    (TextPrenet + PositionalEncoding, src/module.py:265-267)
+ *   4  dropout(X * pro_scale + pe[*pos], pro_drop2)                                           (PositionalEncoding on the speech prenet output)
+ * With `cache`, output columns >= split_col go to cache[(m*cache_rows + *pos)*ld_cache + n - split_col] (the self-attention K|V of
+ * this position) and Y receives the columns below split_col only. */
+int unast_decode_linear(const float* X, int ldx, int64_t x_pos_stride, const float* W, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K,
+                        int act, float drop_p, unsigned int seed, unsigned int stream_id, const float* R, int ldr,
+                        int prologue, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                        const int64_t* tokens, int ld_tok, const float* emb, const float* pe, float pro_scale,
+                        float pro_drop1, unsigned int pro_stream1, float pro_drop2, unsigned int pro_stream2,
+                        float* xn_out, int ld_xn,
+                        float* cache, int ld_cache, int cache_rows, int split_col, const int64_t* pos, hipStream_t stream);
+/* One query per (sequence, head) against cached keys/values (head dim 64): O[b, 64h..] = dropout(softmax(scale * q.K^T over the
+ * first n_b of the rows_per_seq cached rows of sequence b)) . V with n_b = lens[b], or -- lens NULL -- min(stop_lens[b]+1, *pos+1),
+ * the reference's dec_mask (src/network.py:226-231, 461-465): the attention of torch's multi_head_attention_forward as the
+ * reference's decoder layers call it at the last position of the prefix (src/network.py:232, 466). */
+int unast_decode_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, int rows_per_seq, const int* lens,
+                      const int64_t* stop_lens, const int64_t* pos, float* O, int ldo,
+                      int B, int H, float scale, float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);
+/* End of a position: prediction -> position *pos+1 (tokens[b,*pos+1] = argmax logits; outputs[b,*pos+1,:] / stops[b,*pos+1] =
+ * head[b,:M] / head[b,M]), stop rule (argmax == EOS, src/network.py:470-472; sigmoid(stop) >= .5, src/network.py:240-243), then
+ * *pos += 1 and *epoch += 1 (epoch may be NULL; see unast_set_rng_epoch). */
 int unast_decode_end_text(const float* logits, int ld, int V, int B, int64_t* tokens, int ld_tok, int64_t* stop_lens, int64_t max_len, int eos,
                           int64_t* pos, int* epoch, hipStream_t stream);
 int unast_decode_end_speech(const float* head, int ld, int M, int B, float* outputs, int ld_out, float* stops, int ld_stop, int64_t* stop_lens,
                             int64_t max_len, int64_t* pos, int* epoch, hipStream_t stream);
-/* Latency-built contraction for the few rows of one decoding position: Y[M,N] = epilogue(X'[M,K] . W[N,K]^T), epilogue as
- * unast_gemm (bias, act 1 = ReLU, dropout, + R).  X' = X, or LayerNorm(X) over K <= 256 features when ln_gamma/ln_beta are given
- * (the decoder layers' norm1/2/3, src/module.py:282-291 via nn.TransformerDecoderLayer; xn_out, if not NULL, receives the
- * normalised rows).  With `cache`, output columns >= split_col go to cache[(m*cache_rows + *pos)*ld_cache + n - split_col] (the
- * self-attention K|V of this position; *pos is read on the device) and Y receives the columns below split_col only. */
-int unast_decode_linear(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K, int act,
-                        float drop_p, unsigned int seed, unsigned int stream_id, const float* R, int ldr,
-                        const float* ln_gamma, const float* ln_beta, float ln_eps, float* xn_out, int ld_xn,
-                        float* cache, int ld_cache, int cache_rows, int split_col, const int64_t* pos, hipStream_t stream);
-/* One query per (sequence, head) against cached keys/values (head dim 64): O[b, 64h..] = dropout(softmax(scale * q.K^T over the
- * first lens[b] of the rows_per_seq cached rows of sequence b)) . V  -- the attention of torch's multi_head_attention_forward as
- * the reference's decoder layers call it at the last position of the prefix (src/network.py:232, 466). */
-int unast_decode_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, int rows_per_seq, const int* lens, float* O, int ldo,
-                      int B, int H, float scale, float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);
 /* a *= alpha: averaging of all-reduced gradients across data-parallel ranks (new vs. the single-device reference). */
 int unast_scale_inplace(float* a, float alpha, int64_t n, hipStream_t stream);
 /* dst[:, :cols] += src[:, :cols] with independent row strides (autograd's add for padded gradient buffers). */

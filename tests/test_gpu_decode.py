@@ -88,7 +88,7 @@ def test_decode_attn(B, H, Tcap, drop):
     lens[-1] = 1
     kvd = kv.to(D).view(B * Tcap, 2 * E)
     O = torch.zeros(B, E, device=D)
-    ops.decode_attn(q.to(D), kvd[:, :E], kvd[:, E:], Tcap, lens.to(D), O, H, drop_p=drop, seed=9, stream_id=2)
+    ops.decode_attn(q.to(D), kvd[:, :E], kvd[:, E:], Tcap, O, H, lens=lens.to(D), drop_p=drop, seed=9, stream_id=2)
     # the general attention kernel with one query per sequence draws the same mask
     O2 = torch.zeros(B, E, device=D)
     lse = torch.zeros(B, H, 1, device=D)
@@ -104,3 +104,57 @@ def test_decode_attn(B, H, Tcap, drop):
                 vv = kv[b, :n, E + 64 * h:E + 64 * h + 64].double()
                 ref[b, 64 * h:64 * h + 64] = torch.softmax(kk @ qq * 0.125, 0) @ vv
         assert relerr(O, ref) < 1e-5
+    # valid length from the device-resident position and stop lengths: min(stop + 1, pos + 1)
+    pos = torch.tensor([min(20, Tcap - 1)], dtype=torch.int64, device=D)
+    stop = torch.full((B,), Tcap, dtype=torch.int64)
+    stop[-1] = 3
+    O3, O4 = torch.zeros(B, E, device=D), torch.zeros(B, E, device=D)
+    ops.decode_attn(q.to(D), kvd[:, :E], kvd[:, E:], Tcap, O3, H, stop_lens=stop.to(D), pos=pos)
+    ops.decode_attn(q.to(D), kvd[:, :E], kvd[:, E:], Tcap, O4, H, lens=torch.minimum(stop + 1, pos.cpu() + 1).to(torch.int32).to(D))
+    assert torch.equal(O3, O4)
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_decode_linear_row_producers_match_the_standalone_kernels(drop):
+    """Embedding + positional encoding, positional encoding alone and LayerNorm + dropout produced inside the contraction give
+    what embed_fwd / posenc_fwd / layernorm_fwd / leaky_dropout followed by the plain contraction give (same dropout streams)."""
+    import math
+    from unast_amd import ops
+    B, E, N, T, V = 7, 256, 96, 12, 46
+    g = torch.Generator().manual_seed(21)
+    tokens = torch.randint(0, V, (B, T), generator=g).to(D)
+    emb, pe = torch.randn(V, E, generator=g).to(D), torch.randn(40, E, generator=g).to(D)
+    W, b = (torch.randn(N, E, generator=g) * 0.1).to(D), torch.randn(N, generator=g).to(D)
+    pos = torch.tensor([5], dtype=torch.int64, device=D)
+    sc = math.sqrt(E)
+    # embedding + positional encoding
+    y, xn = torch.zeros(B, N, device=D), torch.zeros(B, E, device=D)
+    ops.decode_linear(None, W, b, y, embed=(tokens, emb, pe, sc, (drop, 3), (drop, 4)), xn_out=xn, seed=17, pos=pos)
+    x0, x1, y_ref = torch.zeros(B, E, device=D), torch.zeros(B, E, device=D), torch.zeros(B, N, device=D)
+    ops.embed_fwd(tokens[:, 5].contiguous(), emb, x0, 1, drop_p=drop, seed=17, stream_id=3)
+    ops.posenc_fwd(x0, pe[5:6], x1, 1, sc, drop_p=drop, seed=17, stream_id=4)
+    ops.decode_linear(x1, W, b, y_ref)
+    assert relerr(xn, x1.cpu()) < 1e-6 and relerr(y, y_ref.cpu()) < 1e-5
+    # positional encoding of given rows, rows taken from a [B, T, K] buffer at the position
+    frames = torch.randn(B, T, E, generator=g).to(D)
+    y2, xn2 = torch.zeros(B, N, device=D), torch.zeros(B, E, device=D)
+    ops.decode_linear(frames[:, 5].contiguous(), W, b, y2, posenc=(pe, sc, (drop, 6)), xn_out=xn2, seed=17, pos=pos)
+    ops.posenc_fwd(frames[:, 5].contiguous(), pe[5:6], x1, 1, sc, drop_p=drop, seed=17, stream_id=6)
+    ops.decode_linear(x1, W, b, y_ref)
+    assert relerr(xn2, x1.cpu()) < 1e-6 and relerr(y2, y_ref.cpu()) < 1e-5
+    y3 = torch.zeros(B, N, device=D)
+    ops.decode_linear(None, W, b, y3, x_frames=frames, pos=pos)
+    ops.decode_linear(frames[:, 5].contiguous(), W, b, y_ref)
+    assert torch.equal(y3, y_ref)
+    # LayerNorm + dropout
+    z = (torch.randn(B, E, generator=g) * 2 + .5).to(D)
+    gam, bet = (torch.rand(E, generator=g) + .5).to(D), torch.randn(E, generator=g).to(D)
+    y4 = torch.zeros(B, N, device=D)
+    ops.decode_linear(z, W, b, y4, ln=(gam, bet), ln_drop=(drop, 8), seed=17)
+    xl, mean, rstd, xd = torch.zeros(B, E, device=D), torch.zeros(B, device=D), torch.zeros(B, device=D), torch.zeros(B, E, device=D)
+    ops.layernorm_fwd(z, gam, bet, xl, mean, rstd)
+    ops.leaky_dropout(xl, None, xd, 1.0, drop_p=drop, seed=17, stream_id=8)
+    ops.decode_linear(xd, W, b, y_ref)
+    assert relerr(y4, y_ref.cpu()) < 1e-5
+    if drop > 0:
+        assert torch.equal(y4 == 0, y_ref == 0) or relerr(y4, y_ref.cpu()) < 1e-5

@@ -24,7 +24,7 @@ PRESPLIT_WEIGHTS = os.environ.get("UNAST_PRESPLIT", "1") != "0"
 # those functions are always single-stream.
 SIDE_STREAMS = os.environ.get("UNAST_SIDE_STREAMS", "1") != "0"
 
-# infer_sequence replays ONE captured HIP graph per decoded position (the step is ~39 small launches and otherwise bound by
+# infer_sequence replays ONE captured HIP graph per decoded position (the step is ~35 small launches and otherwise bound by
 # host launch overhead); 0 = launch every kernel from Python.
 DECODE_GRAPH = os.environ.get("UNAST_DECODE_GRAPH", "1") != "0"
 

@@ -285,107 +285,12 @@ __global__ __launch_bounds__(256) void mask_by_len_kernel(float* __restrict__ x,
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Bookkeeping of one autoregressive decoding position with the position itself in device memory (the step is replayed from
-// a captured graph: unast_amd/inference.py).  These replace ~17 one-element torch ops per position (gathers, minimum,
-// compares, where, index copies, increments), each of which cost a kernel dispatch on a dispatch-latency-bound path.
-//   begin: valid self-attention length per sequence min(pos+1, stop_len+1) (src/network.py:226-231, 461-465: dec_mask),
-//          the positional-encoding row of this position, and the decoder input of this position (token id / mel frame).
-//   end:   writes the prediction to position pos+1, applies the stop rule (argmax == EOS, src/network.py:470-472;
-//          sigmoid(stop) >= .5, src/network.py:240-243), then advances pos and the RNG epoch.  One workgroup: the increments
-//          come after a barrier behind every read of pos.
-// ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void decode_begin_kernel(const int64_t* __restrict__ pos, const int64_t* __restrict__ stop_lens, int B,
-                                                           int* __restrict__ lens_self, const float* __restrict__ pe, int D, float* __restrict__ pe_row,
-                                                           const int64_t* __restrict__ tokens, int ld_tok, int64_t* __restrict__ cur_tok,
-                                                           const float* __restrict__ frames, int ld_frame, int M, float* __restrict__ cur_frame) {
-    const int64_t p = pos[0];
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < B) {
-        const int64_t a = stop_lens[t] + 1, b = p + 1;
-        lens_self[t] = (int)(a < b ? a : b);
-        if (tokens) cur_tok[t] = tokens[(size_t)t * ld_tok + p];
-    }
-    if (t < D) pe_row[t] = pe[(size_t)p * D + t];
-    if (frames)
-        for (int i = t; i < B * M; i += gridDim.x * 256) {
-            const int b = i / M, c = i - b * M;
-            cur_frame[i] = frames[(size_t)b * ld_frame + (size_t)p * M + c];
-        }
-}
-
-__global__ __launch_bounds__(256) void decode_end_text_kernel(const float* __restrict__ logits, int ld, int V, int B, int64_t* __restrict__ tokens, int ld_tok,
-                                                              int64_t* __restrict__ stop_lens, int64_t max_len, int eos, int64_t* __restrict__ pos,
-                                                              int* __restrict__ epoch) {
-    const int64_t p = pos[0];
-    for (int b = threadIdx.x; b < B; b += 256) {
-        const float* xr = logits + (size_t)b * ld;
-        float best = xr[0];
-        int bi = 0;
-        for (int c = 1; c < V; ++c) {                   // first maximum, as torch.argmax
-            const float v = xr[c];
-            if (v > best) { best = v; bi = c; }
-        }
-        tokens[(size_t)b * ld_tok + p + 1] = bi;
-        if (bi == eos && stop_lens[b] == max_len) stop_lens[b] = p + 1;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { pos[0] = p + 1; if (epoch) epoch[0] += 1; }
-}
-
-__global__ __launch_bounds__(256) void decode_end_speech_kernel(const float* __restrict__ head, int ld, int M, int B, float* __restrict__ outputs, int ld_out,
-                                                                float* __restrict__ stops, int ld_stop, int64_t* __restrict__ stop_lens, int64_t max_len,
-                                                                int64_t* __restrict__ pos, int* __restrict__ epoch) {
-    const int64_t p = pos[0];
-    for (int i = threadIdx.x; i < B * M; i += 256) {
-        const int b = i / M, c = i - b * M;
-        outputs[(size_t)b * ld_out + (size_t)(p + 1) * M + c] = head[(size_t)b * ld + c];
-    }
-    for (int b = threadIdx.x; b < B; b += 256) {
-        const float x = head[(size_t)b * ld + M];
-        stops[(size_t)b * ld_stop + p + 1] = x;
-        if (1.f / (1.f + expf(-x)) >= .5f && stop_lens[b] == max_len) stop_lens[b] = p + 1;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { pos[0] = p + 1; if (epoch) epoch[0] += 1; }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------
 extern "C" int unast_argmax_rows(const float* x, int ld, int rows, int cols, int64_t* out, hipStream_t stream) {
     UNAST_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "unast_argmax_rows: bad arguments");
     hipLaunchKernelGGL(argmax_rows_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, x, ld, rows, cols, out);
     return unast_check_launch("unast_argmax_rows");
-}
-
-extern "C" int unast_decode_begin(const int64_t* pos, const int64_t* stop_lens, int B, int* lens_self, const float* pe, int D, float* pe_row,
-                                  const int64_t* tokens, int ld_tok, int64_t* cur_tok, const float* frames, int ld_frame, int M, float* cur_frame,
-                                  hipStream_t stream) {
-    UNAST_REQUIRE(pos && stop_lens && lens_self && pe && pe_row && B > 0 && D > 0, "unast_decode_begin: bad arguments");
-    UNAST_REQUIRE((tokens && cur_tok) || (frames && cur_frame && M > 0), "unast_decode_begin: give tokens+cur_tok or frames+cur_frame");
-    int n = B > D ? B : D;
-    if (frames && B * M > n) n = B * M;
-    int blocks = (n + 255) / 256;
-    if (blocks > 64) blocks = 64;
-    UNAST_REQUIRE(blocks * 256 >= (B > D ? B : D), "unast_decode_begin: B, D <= 16384");
-    hipLaunchKernelGGL(decode_begin_kernel, dim3(blocks), dim3(256), 0, stream, pos, stop_lens, B, lens_self, pe, D, pe_row, tokens, ld_tok, cur_tok, frames,
-                       ld_frame, M, cur_frame);
-    return unast_check_launch("unast_decode_begin");
-}
-
-extern "C" int unast_decode_end_text(const float* logits, int ld, int V, int B, int64_t* tokens, int ld_tok, int64_t* stop_lens, int64_t max_len, int eos,
-                                     int64_t* pos, int* epoch, hipStream_t stream) {
-    UNAST_REQUIRE(logits && tokens && stop_lens && pos && B > 0 && V > 0 && ld >= V && ld_tok > max_len, "unast_decode_end_text: bad arguments");
-    hipLaunchKernelGGL(decode_end_text_kernel, dim3(1), dim3(256), 0, stream, logits, ld, V, B, tokens, ld_tok, stop_lens, max_len, eos, pos, epoch);
-    return unast_check_launch("unast_decode_end_text");
-}
-
-extern "C" int unast_decode_end_speech(const float* head, int ld, int M, int B, float* outputs, int ld_out, float* stops, int ld_stop, int64_t* stop_lens,
-                                       int64_t max_len, int64_t* pos, int* epoch, hipStream_t stream) {
-    UNAST_REQUIRE(head && outputs && stops && stop_lens && pos && B > 0 && M > 0 && ld > M && ld_out >= (max_len + 1) * M && ld_stop > max_len,
-                  "unast_decode_end_speech: bad arguments");
-    hipLaunchKernelGGL(decode_end_speech_kernel, dim3(1), dim3(256), 0, stream, head, ld, M, B, outputs, ld_out, stops, ld_stop, stop_lens, max_len, pos, epoch);
-    return unast_check_launch("unast_decode_end_speech");
 }
 
 extern "C" int unast_mask_by_len(float* x, const int64_t* lens, int B, int T, int D, hipStream_t stream) {

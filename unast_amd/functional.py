@@ -567,15 +567,15 @@ def lstm_discriminator(cx, tape, m, x, lens, Bd, T, need_input_grad=True):
 # ---------------------------------------------------------------------------------------------------------------
 # Inference-only helpers used by unast_amd.inference (no tape)
 # ---------------------------------------------------------------------------------------------------------------
-def speech_prenet_step(cx, m, frame2d):
-    """SpeechPrenet on [B, num_mels] rows (one decoder input position per sequence)."""
+def speech_prenet_step(cx, m, frames, pos_t):
+    """SpeechPrenet on the frames [B, T, num_mels] at the device-resident position pos_t (one decoder input per sequence)."""
     a = m.args
-    N = frame2d.shape[0]
+    N = frames.shape[0]
     W1, b1 = cx.P["speech_m.prenet.layer.fc1.linear_layer.weight"], cx.P["speech_m.prenet.layer.fc1.linear_layer.bias"]
     W2, b2 = cx.P["speech_m.prenet.layer.fc2.linear_layer.weight"], cx.P["speech_m.prenet.layer.fc2.linear_layer.bias"]
-    h1 = _empty(N, W1.shape[0], like=frame2d)
-    ops.decode_linear(frame2d, W1, b1, h1, act=1, drop_p=cx.p(a.s_pre_drop), seed=cx.seed, stream_id=cx.stream())
-    h2 = _empty(N, W2.shape[0], like=frame2d)
+    h1 = _empty(N, W1.shape[0], like=frames)
+    ops.decode_linear(None, W1, b1, h1, act=1, drop_p=cx.p(a.s_pre_drop), seed=cx.seed, stream_id=cx.stream(), x_frames=frames, pos=pos_t)
+    h2 = _empty(N, W2.shape[0], like=frames)
     ops.decode_linear(h1, W2, b2, h2, act=1)
     return h2
 

@@ -8,10 +8,11 @@ cache, the cross-attention K/V of the memory are projected once per layer, and t
 Positions generated after a sequence has stopped are masked as padded keys exactly as the reference's `dec_mask` does:
 they form a suffix, so the mask is a per-sequence valid length min(i+1, stop_len+1).
 
-One decoded position is ~39 small launches on B rows each (csrc/decode.hip: contractions and single-query attention built for
-latency), i.e. bound by launch overhead.  The step therefore keeps its position in DEVICE memory (decode_begin / decode_end_*
-read and advance it, the in-projection appends K|V at it), so that it can be captured once as a HIP graph and replayed per
-position (`config.DECODE_GRAPH`); dropout streams of replayed launches are varied by the device-side epoch counter of
+One decoded position is ~35 small launches on B rows each (csrc/decode.hip: contractions and single-query attention built for
+latency; embedding, positional encoding and the LayerNorms are produced inside the contraction that consumes them, the K|V of
+the new position go straight from the in-projection into the cache), i.e. bound by launch overhead.  The step therefore keeps
+its position in DEVICE memory, so that it can be captured once as a HIP graph and replayed per position
+(`config.DECODE_GRAPH`); dropout streams of replayed launches are varied by the device-side epoch counter of
 `ops.rng_epoch_counter()`.  Two generations that do not depend on each other (the two directions of a cross-model step) are
 decoded in lock-step from one graph with two branches (`run_pair`).
 
@@ -53,22 +54,22 @@ class _LayerStep:
     def norm_out(self):
         return (self.cx.P[self.lp + "norm3.weight"], self.cx.P[self.lp + "norm3.bias"])
 
-    def __call__(self, x, ln_in, pos_t, lens_self):
-        """x: the layer input [B,E] -- already normalised if ln_in is None, else the previous layer's pre-norm3 sum with
-        ln_in = (gamma, beta).  Returns this layer's pre-norm3 sum; the consumer applies norm_out()."""
+    def __call__(self, x, pro, pos_t, stop_lens):
+        """x: the layer input [B,E]; pro: how the first contraction produces its input rows from x (kwargs of
+        ops.decode_linear: {} = x as it is, ln=(gamma, beta) of the previous layer's norm3 on its pre-norm sum, embed=/posenc= for
+        the first layer).  Returns this layer's pre-norm3 sum; the consumer applies norm_out()."""
         cx, lp, B, E, H = self.cx, self.lp, self.B, self.E, self.H
-        P, p, dev = cx.P, self.p, x.device
+        P, p, dev = cx.P, self.p, self.cache.device
         # --- self-attention over the cache (positions 0..pos; stopped sequences keep their frozen valid length)
         q = _empty(B, E, dev=dev)
-        if ln_in is not None:
-            xn = _empty(B, E, dev=dev)
-        ops.decode_linear(x, P[lp + "self_attn.in_proj_weight"], P[lp + "self_attn.in_proj_bias"], q, ln=ln_in, xn_out=xn if ln_in is not None else None,
-                          cache=self.cache, split_col=E, pos=pos_t)              # q -> q, K|V -> cache[:, pos]
-        if ln_in is not None:
+        xn = _empty(B, E, dev=dev) if pro else None
+        ops.decode_linear(x, P[lp + "self_attn.in_proj_weight"], P[lp + "self_attn.in_proj_bias"], q, xn_out=xn, seed=cx.seed,
+                          cache=self.cache, split_col=E, pos=pos_t, **pro)       # q -> q, K|V -> cache[:, pos]
+        if pro:
             x = xn
         kv2d = self.cache.view(B * self.Tcap, 2 * E)
         O = _empty(B, E, dev=dev)
-        ops.decode_attn(q, kv2d[:, :E], kv2d[:, E:], self.Tcap, lens_self, O, H, drop_p=p, seed=cx.seed, stream_id=cx.stream())
+        ops.decode_attn(q, kv2d[:, :E], kv2d[:, E:], self.Tcap, O, H, stop_lens=stop_lens, pos=pos_t, drop_p=p, seed=cx.seed, stream_id=cx.stream())
         z1 = _empty(B, E, dev=dev)
         ops.decode_linear(O, P[lp + "self_attn.out_proj.weight"], P[lp + "self_attn.out_proj.bias"], z1, drop_p=p, seed=cx.seed, stream_id=cx.stream(), R=x)
         # --- cross-attention over the memory: q = W_q norm1(z1)
@@ -76,7 +77,7 @@ class _LayerStep:
         q2, x1 = _empty(B, E, dev=dev), _empty(B, E, dev=dev)
         ops.decode_linear(z1, Wc[:E], bc[:E], q2, ln=(P[lp + "norm1.weight"], P[lp + "norm1.bias"]), xn_out=x1)
         O2 = _empty(B, E, dev=dev)
-        ops.decode_attn(q2, self.memkv[:, :E], self.memkv[:, E:], self.Tk, self.lens_mem, O2, H, drop_p=p, seed=cx.seed, stream_id=cx.stream())
+        ops.decode_attn(q2, self.memkv[:, :E], self.memkv[:, E:], self.Tk, O2, H, lens=self.lens_mem, drop_p=p, seed=cx.seed, stream_id=cx.stream())
         z2 = _empty(B, E, dev=dev)
         ops.decode_linear(O2, P[lp + "multihead_attn.out_proj.weight"], P[lp + "multihead_attn.out_proj.bias"], z2, drop_p=p, seed=cx.seed, stream_id=cx.stream(), R=x1)
         # --- feed-forward on norm2(z2)
@@ -89,28 +90,12 @@ class _LayerStep:
         return z3
 
 
-def _run_layers(layers, x, pos_t, lens_self):
+def _run_layers(layers, x, pro, pos_t, stop_lens):
     """The decoder stack on one position; returns (pre-norm sum of the last layer, that norm's (gamma, beta))."""
-    ln = None
     for L in layers:
-        x = L(x, ln, pos_t, lens_self)
-        ln = L.norm_out()
-    return x, ln
-
-
-def _layernorm(z, ln):
-    y = torch.empty_like(z)
-    mean = _empty(z.shape[0], dev=z.device)
-    rstd = _empty(z.shape[0], dev=z.device)
-    ops.layernorm_fwd(z, ln[0], ln[1], y, mean, rstd)
-    return y
-
-
-def _posenc_step(cx, x, pe_row):
-    """PositionalEncoding for one position: x*sqrt(d) + pe[pos], dropout 0.1 (src/module.py:265-267)."""
-    y = torch.empty_like(x)
-    ops.posenc_fwd(x, pe_row, y, 1, math.sqrt(x.shape[1]), drop_p=cx.p(0.1), seed=cx.seed, stream_id=cx.stream())
-    return y
+        x = L(x, pro, pos_t, stop_lens)
+        pro = {"ln": L.norm_out()}
+    return x, pro["ln"]
 
 
 _CAPTURE_STREAM = {}
@@ -137,42 +122,9 @@ def _capture(fn, pool=None):
     return graph
 
 
-def _run_steps(step, pos_t, stop_lens, max_len, reset):
-    """Runs `step(epoch)` (one decoded position; advances pos_t -- and the RNG epoch counter if given -- on the device) until
-    every sequence has stopped or max_len steps.  Returns the number of steps executed.  With config.DECODE_GRAPH the step is
-    captured once and replayed."""
-    def all_stopped():
-        return not bool((stop_lens == max_len).any())                            # the only host read-back of the loop
-    graph = None
-    if config.DECODE_GRAPH and max_len >= 2 * SYNC_EVERY:
-        ctr = ops.rng_epoch_counter()
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):                                            # warm-up outside capture (lazy initialisations)
-            step(None)
-        cur.wait_stream(side)
-        reset()
-        graph = _capture(lambda: step(ctr))                                      # ctr: fresh dropout streams at the next position
-    steps = 0
-    try:
-        for i in range(max_len):
-            if graph is not None:
-                graph.replay()
-            else:
-                step(None)
-            steps = i + 1
-            if steps % SYNC_EVERY == 0 and all_stopped():
-                break
-    finally:
-        if graph is not None:
-            ops.rng_epoch_counter().zero_()                                      # forward/backward pairs must see epoch 0
-    return steps
-
-
 class _Generation:
-    """One autoregressive generation in flight: `step(epoch)` decodes one position (state in device memory), `reset()` rewinds
-    it, `finish(steps)` turns the buffers into the reference's return values."""
+    """One autoregressive generation in flight: `step(epoch)` issues the launches of one position (state in device memory),
+    `reset()` rewinds it, `finish(steps)` turns the buffers into the reference's return values."""
 
     def __init__(self, step, reset, finish, pos_t, stop_lens, max_len):
         self.step, self.reset, self.finish = step, reset, finish
@@ -180,8 +132,38 @@ class _Generation:
         self.steps = 0
 
     def run(self):
-        self.steps = _run_steps(self.step, self.pos_t, self.stop_lens, self.max_len, self.reset)
-        return self.finish(self.steps)
+        """Decodes until every sequence has stopped or max_len positions.  With config.DECODE_GRAPH the step is captured once and
+        replayed."""
+        stop_lens, max_len = self.stop_lens, self.max_len
+
+        def all_stopped():
+            return not bool((stop_lens == max_len).any())                        # the only host read-back of the loop
+        ctr = ops.rng_epoch_counter()
+        one = None
+        if config.DECODE_GRAPH and max_len >= 2 * SYNC_EVERY:
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):                                        # warm-up outside capture (lazy initialisations)
+                self.step(None)
+            cur.wait_stream(side)
+            self.reset()
+            one = _capture(lambda: self.step(ctr)).replay                        # ctr: fresh dropout streams at the next position
+        steps = 0
+        try:
+            for i in range(max_len):
+                if one is not None:
+                    one()
+                else:
+                    self.step(None)
+                steps = i + 1
+                if steps % SYNC_EVERY == 0 and all_stopped():
+                    break
+        finally:
+            if one is not None:
+                ctr.zero_()                                                      # forward/backward pairs must see epoch 0
+        self.steps = steps
+        return self.finish(steps)
 
 
 _PAIR_STREAM = {}
@@ -189,9 +171,9 @@ _PAIR_STREAM = {}
 
 def run_pair(ga, gb):
     """Runs two independent generations in lock-step: one captured graph per position with the two steps on two branches
-    (each step is a chain of ~39 dependent, chip-under-filling launches, i.e. bound by dispatch latency, so the two chains
-    overlap almost perfectly).  When one of them is done the other continues with a graph of its own.  The dropout epoch of
-    both is the position, exactly as when they run one after the other.  Returns (ga.finish(..), gb.finish(..))."""
+    (a step is a chain of ~35 dependent, chip-under-filling launches, i.e. bound by latency, so the two chains overlap almost
+    perfectly).  When one of them is done the other continues with a graph of its own.  The dropout epoch of both is the
+    position, exactly as when they run one after the other.  Returns (ga.finish(..), gb.finish(..))."""
     if not (config.DECODE_GRAPH and min(ga.max_len, gb.max_len) >= 2 * SYNC_EVERY):
         return ga.run(), gb.run()
     ctr = ops.rng_epoch_counter()
@@ -278,20 +260,10 @@ def text_generation(m, cx, memory, lens_mem, max_len):
         stop_lens.fill_(max_len)
 
     def step(epoch):
-        cur = torch.empty(B, dtype=torch.int64, device=dev)
-        lens_self = torch.empty(B, dtype=torch.int32, device=dev)                # dec_mask as a valid-prefix length
-        pe_row = _empty(1, E, dev=dev)
-        ops.decode_begin(pos_t, stop_lens, lens_self, m.pe, pe_row, tokens=tokens, cur_tok=cur)
-        x = _empty(B, E, dev=dev)
-        ops.embed_fwd(cur, Emb, x, 1, drop_p=cx.p(a.t_pre_drop), seed=cx.seed, stream_id=cx.stream())
-        x = _posenc_step(cx, x, pe_row)
-        z, ln = _run_layers(layers, x, pos_t, lens_self)
-        if pt > 0:                                                               # dropout sits between the last norm and fc1
-            x = _layernorm(z, ln)
-            xd = torch.empty_like(x)
-            ops.leaky_dropout(x, None, xd, 1.0, drop_p=pt, seed=cx.seed, stream_id=cx.stream())
-            z, ln = xd, None
-        ops.decode_linear(z, P["text_m.postnet.fc1.weight"], P["text_m.postnet.fc1.bias"], logits, ln=ln)
+        # TextPrenet (embedding, dropout) + PositionalEncoding (src/module.py:265-267) are produced inside the first contraction
+        first = {"embed": (tokens, Emb, m.pe, math.sqrt(E), (cx.p(a.t_pre_drop), cx.stream()), (cx.p(0.1), cx.stream()))}
+        z, ln = _run_layers(layers, None, first, pos_t, stop_lens)
+        ops.decode_linear(z, P["text_m.postnet.fc1.weight"], P["text_m.postnet.fc1.bias"], logits, ln=ln, ln_drop=(pt, cx.stream()), seed=cx.seed)
         ops.decode_end_text(logits, V, tokens, stop_lens, max_len, EOS_IDX, pos_t, epoch)   # argmax -> tokens[:, pos+1]; stop rule; pos += 1
 
     def finish(steps):
@@ -335,13 +307,9 @@ def speech_generation(m, cx, memory, lens_mem, max_len, speech_prenet_step, post
         stop_lens.fill_(max_len)
 
     def step(epoch):
-        frame = _empty(B, M, dev=dev)
-        lens_self = torch.empty(B, dtype=torch.int32, device=dev)
-        pe_row = _empty(1, E, dev=dev)
-        ops.decode_begin(pos_t, stop_lens, lens_self, m.pe, pe_row, frames=outputs, cur_frame=frame)
-        x = speech_prenet_step(cx, frame)
-        x = _posenc_step(cx, x, pe_row)
-        z, ln = _run_layers(layers, x, pos_t, lens_self)
+        x = speech_prenet_step(cx, outputs, pos_t)                                # on the frame at position pos
+        first = {"posenc": (m.pe, math.sqrt(E), (cx.p(0.1), cx.stream()))}
+        z, ln = _run_layers(layers, x, first, pos_t, stop_lens)
         ops.decode_linear(z, Wh, bh, head, ln=ln)
         ops.decode_end_speech(head, M, outputs, stops, stop_lens, max_len, pos_t, epoch)   # frame/stop -> pos+1; stop rule (src/network.py:242)
 

@@ -271,7 +271,7 @@ class SpeechTransformer(AutoEncoderNet):
         max_len = max_len or self.infer_max_len
         from .inference import speech_generation
         return speech_generation(self, self._ctx(), memory.detach(), masks[1], max_len,
-                                 lambda cx, fr: F.speech_prenet_step(cx, self, fr), lambda cx, mel: F.speech_postnet_residual(cx, self, mel))
+                                 lambda cx, fr, pos: F.speech_prenet_step(cx, self, fr, pos), lambda cx, mel: F.speech_postnet_residual(cx, self, mel))
 
 
 class LSTMDiscriminator(_Side):

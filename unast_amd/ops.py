@@ -280,33 +280,52 @@ def mask_by_len(x3d, lens_i64):
     check(lib().unast_mask_by_len(_p(x3d), _p(lens_i64), B, T, D, _stream()), "unast_mask_by_len")
 
 
-def decode_linear(X, W, bias, Y, act=0, drop_p=0.0, seed=0, stream_id=0, R=None, ln=None, xn_out=None, cache=None, split_col=0, pos=None):
-    """Y = epilogue(X' W^T) for the rows of one decoding position (csrc/decode.hip); ln = (gamma, beta) normalises X first."""
-    M, K = X.shape
-    N = W.shape[0]
-    assert W.shape[1] == K and X.stride(1) == 1 and W.stride(1) == 1
-    g, b = ln if ln is not None else (None, None)
-    check(lib().unast_decode_linear(_p(X), X.stride(0), _p(W), W.stride(0), _p(bias), _p(Y), Y.stride(0) if Y is not None else 0, M, N, K, act,
+PRO_NONE, PRO_LN, PRO_LN_DROP, PRO_EMBED, PRO_POSENC = 0, 1, 2, 3, 4
+def decode_linear(X, W, bias, Y, act=0, drop_p=0.0, seed=0, stream_id=0, R=None, ln=None, ln_drop=None, embed=None, posenc=None, xn_out=None,
+                  cache=None, split_col=0, pos=None, x_frames=None):
+    """Y = epilogue(X' W^T) for the rows of one decoding position (csrc/decode.hip).  X' = X, or
+    ln=(gamma, beta): LayerNorm(X);  + ln_drop=(p, stream): dropout of that;
+    embed=(tokens [B,T], table, pe, scale, (p1, stream1), (p2, stream2)): dropout(dropout(table[tokens[:, pos]]) * scale + pe[pos]);
+    posenc=(pe, scale, (p2, stream2)): dropout(X * scale + pe[pos]).
+    x_frames: X is a [B, T, K] buffer and the rows are its slice at the device-resident position `pos`."""
+    N, K = W.shape
+    assert W.stride(1) == 1
+    pro, g, b, tokens, ld_tok, emb, pe, scale, d1, d2 = PRO_NONE, None, None, None, 0, None, None, 1.0, (0.0, 0), (0.0, 0)
+    if ln is not None:
+        g, b = ln
+        pro = PRO_LN
+        if ln_drop is not None and ln_drop[0] > 0:
+            pro, d2 = PRO_LN_DROP, ln_drop
+    elif embed is not None:
+        tokens, emb, pe, scale, d1, d2 = embed
+        pro, ld_tok = PRO_EMBED, tokens.stride(0)
+    elif posenc is not None:
+        pe, scale, d2 = posenc
+        pro = PRO_POSENC
+    if x_frames is not None:
+        X, ldx, xps, M = x_frames, x_frames.stride(0), x_frames.stride(1), x_frames.shape[0]
+        assert x_frames.stride(2) == 1 and x_frames.shape[2] == K
+    elif X is not None:
+        assert X.shape[1] == K and X.stride(1) == 1
+        ldx, xps, M = X.stride(0), 0, X.shape[0]
+    else:
+        ldx, xps, M = 0, 0, tokens.shape[0]
+    check(lib().unast_decode_linear(_p(X), ldx, xps, _p(W), W.stride(0), _p(bias), _p(Y), Y.stride(0) if Y is not None else 0, M, N, K, act,
                                     float(drop_p), seed, stream_id, _p(R), R.stride(0) if R is not None else 0,
-                                    _p(g), _p(b), 1e-5, _p(xn_out), xn_out.stride(0) if xn_out is not None else 0,
+                                    pro, _p(g), _p(b), 1e-5, _p(tokens), ld_tok, _p(emb), _p(pe), float(scale),
+                                    float(d1[0]), d1[1], float(d2[0]), d2[1],
+                                    _p(xn_out), xn_out.stride(0) if xn_out is not None else 0,
                                     _p(cache), cache.stride(1) if cache is not None else 0, cache.shape[1] if cache is not None else 0, split_col, _p(pos),
                                     _stream()), "unast_decode_linear")
 
 
-def decode_attn(Q, K, V, rows_per_seq, lens, O, H, drop_p=0.0, seed=0, stream_id=0):
-    """Single-query attention over cached K/V rows ([B*rows_per_seq, ld] views), head dim 64."""
+def decode_attn(Q, K, V, rows_per_seq, O, H, lens=None, stop_lens=None, pos=None, drop_p=0.0, seed=0, stream_id=0):
+    """Single-query attention over cached K/V rows ([B*rows_per_seq, ld] views), head dim 64; valid keys: lens[b], or
+    min(stop_lens[b] + 1, pos + 1) with both on the device."""
     B = Q.shape[0]
     assert K.stride(0) == V.stride(0) and Q.shape[1] == 64 * H
-    check(lib().unast_decode_attn(_p(Q), Q.stride(0), _p(K), _p(V), K.stride(0), rows_per_seq, _p(lens), _p(O), O.stride(0), B, H, 0.125,
+    check(lib().unast_decode_attn(_p(Q), Q.stride(0), _p(K), _p(V), K.stride(0), rows_per_seq, _p(lens), _p(stop_lens), _p(pos), _p(O), O.stride(0), B, H, 0.125,
                                   float(drop_p), seed, stream_id, _stream()), "unast_decode_attn")
-
-
-def decode_begin(pos, stop_lens, lens_self, pe, pe_row, tokens=None, cur_tok=None, frames=None, cur_frame=None):
-    B = stop_lens.numel()
-    D = pe.shape[1]
-    M = frames.shape[2] if frames is not None else 0
-    check(lib().unast_decode_begin(_p(pos), _p(stop_lens), B, _p(lens_self), _p(pe), D, _p(pe_row), _p(tokens), tokens.stride(0) if tokens is not None else 0,
-                                   _p(cur_tok), _p(frames), frames.stride(0) if frames is not None else 0, M, _p(cur_frame), _stream()), "unast_decode_begin")
 
 
 def decode_end_text(logits, V, tokens, stop_lens, max_len, eos, pos, epoch):
