@@ -51,6 +51,7 @@ class OpTimer:
     def __init__(self, ops_mod, names):
         self.ops, self.names = ops_mod, names
         self.orig, self.events, self.meta = {}, defaultdict(list), {}
+        self.active = True          # event pairs cost ~15 us of host time per launch: the bench switches them on for a sample of the steps
 
     def __enter__(self):
         for n in self.names:
@@ -58,7 +59,7 @@ class OpTimer:
             self.orig[n] = f
 
             def wrapped(*a, __f=f, __n=n, **k):
-                if torch.cuda.is_current_stream_capturing():      # launches recorded into a HIP graph (generation) are not timed
+                if not self.active or torch.cuda.is_current_stream_capturing():   # launches recorded into a HIP graph (generation) are not timed
                     return __f(*a, **k)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -239,9 +240,14 @@ def main():
                   "add_inplace", "add_strided", "specaugment", "disc_gather", "disc_scatter", "speech_loss_fwd", "speech_loss_bwd", "text_loss_fwd",
                   "text_loss_bwd", "bce_logits", "disc_targets", "lstm_fwd", "lstm_bwd", "leaky_dropout", "sumsq", "adamw", "scale_inplace"]
     sync()
+    # HIP-event pairs around every GEMM / attention launch of a step cost ~15 ms of host time per step -- enough to make the host
+    # the bottleneck (40 ms of enqueueing against 36 ms of GPU work) -- so they are on for every `every`-th step of the timed region.
+    every = 1 if (a.steps <= 4 or a.profile_ops) else 5
+    n_timed = len(range(0, a.steps, every))
     with OpTimer(ops, timed) as ot:
         t0 = time.perf_counter()
         for i in range(a.steps):
+            ot.active = (i % every == 0)
             one_step(a.warmup + i)
         t_host = time.perf_counter() - t0          # host-side enqueue time (kernels run asynchronously)
         sync()
@@ -304,7 +310,7 @@ def main():
         roofline = {"kernel": kernel_name, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["calls"], 1), 0),
-                    "launches_per_step": d["calls"] / a.steps, "avg_launch_us": round(d["ms"] * 1e3 / max(d["calls"], 1), 2),
+                    "launches_per_step": d["calls"] / n_timed, "timed_steps": n_timed, "avg_launch_us": round(d["ms"] * 1e3 / max(d["calls"], 1), 2),
                     "concurrent_streams": (4 if config.WGRAD_STREAMS else 3) if config.SIDE_STREAMS else 1,
                     "isolated": (None if not iso else (lambda c, ms, by: {"avg_launch_us": round(ms * 1e3 / max(c, 1), 2), "achieved": round(by / (ms * 1e-3) / 1e9, 1),
                                                                           "frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})(
@@ -312,20 +318,20 @@ def main():
                     "mfma_view": {"achieved_tflops": round(ach, 2), "frac_of_2500_dense_bf16": round(ach / PEAK_MFMA_BF16_TFLOPS, 4),
                                   "mfma_issue_tflops": round(ach * config.NSPLIT, 1), "sustained_mfma_peak_measured_tflops": SUSTAINED_MFMA_TFLOPS},
                     "note": "achieved = algorithmic bytes (fp32 A + B + C and epilogue operands, each once; conv inputs once, not per tap) / HIP-event "
-                            "time of these launches inside the timed region (text side, speech side and discriminator run on three HIP streams and the "
+                            "time of these launches inside the timed region (event pairs on every 5th step when steps > 4, see timed_steps; text side, speech side and discriminator run on three HIP streams and the "
                             "speech side's weight gradients on a fourth, so a launch's duration includes time it shares the chip with kernels of the "
                             "others; `isolated` = the same launches in two extra single-stream steps after the timed region, comparable with profiles/); traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE per launch from "
                             "profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 passes of this command), null if that file is absent; mfma_view: 2MNK "
                             "FLOPs per contraction, each product costs %d bf16 MFMAs in %s mode; sustained peak = tools/mfma_peak.cpp on this chip" % (config.NSPLIT, a.precision),
-                    "families_ms_per_step": {n: round(fam[n]["ms"] / a.steps, 3) for n in fam}}
+                    "families_ms_per_step": {n: round(fam[n]["ms"] / n_timed, 3) for n in fam}}
     else:
         roofline = {"kernel": kernel_name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": d["calls"] / a.steps, "avg_launch_us": round(d["ms"] * 1e3 / max(d["calls"], 1), 2),
+                    "launches_per_step": d["calls"] / n_timed, "timed_steps": n_timed, "avg_launch_us": round(d["ms"] * 1e3 / max(d["calls"], 1), 2),
                     "mfma_issue_frac": round(ach * config.NSPLIT / PEAK_MFMA_BF16_TFLOPS, 4),
                     "note": "achieved = algorithmic FLOPs (4*B*H*Tq*Tk*64 per attention forward, x2.5 backward) / HIP-event time of these launches "
                             "inside the timed region; each product costs %d bf16 MFMAs in %s mode" % (config.NSPLIT, a.precision),
-                    "families_ms_per_step": {n: round(fam[n]["ms"] / a.steps, 3) for n in fam}}
+                    "families_ms_per_step": {n: round(fam[n]["ms"] / n_timed, 3) for n in fam}}
     out = {"metric": "mel-frames/sec/node (train step, gen+disc) at B=32,T_mel=800; 1/2/4/8-GPU scaling",
            "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -350,13 +356,13 @@ def main():
         except Exception as e:  # the checker must never take the bench down
             out["cpu_baseline"] = {"error": repr(e)}
     if a.profile_ops:
-        prof = {n: round(sum(v[1] for v in summ[n].values()) / a.steps, 3) for n in summ}
+        prof = {n: round(sum(v[1] for v in summ[n].values()) / n_timed, 3) for n in summ}
         sys.stderr.write("per-op ms/step: " + json.dumps(dict(sorted(prof.items(), key=lambda kv: -kv[1]))) + "\n")
         for n in ("gemm", "attn_fwd", "attn_bwd"):
             rows = sorted(summ[n].items(), key=lambda kv: -kv[1][1])[:12]
             for k, v in rows:
                 fl = (gemm_flops(k) if n == "gemm" else attn_flops(n, k))
-                sys.stderr.write("  %-9s %-28s calls/step %5.1f  avg %8.1f us  %7.1f TF/s\n" % (n, k, v[0] / a.steps, v[1] * 1e3 / v[0], fl * v[0] / (v[1] * 1e-3) / 1e12))
+                sys.stderr.write("  %-9s %-28s calls/step %5.1f  avg %8.1f us  %7.1f TF/s\n" % (n, k, v[0] / n_timed, v[1] * 1e3 / v[0], fl * v[0] / (v[1] * 1e-3) / 1e12))
     print(json.dumps(out))
 
 
