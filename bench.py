@@ -177,6 +177,7 @@ def main():
                     "separately from the headline metric, which is defined with cm_steps = 0 (SURVEY.md section 8d)")
     ap.add_argument("--cm-max-len", type=int, default=0, help="cap of the autoregressive generation inside the cm sub-step (0 = reference "
                     "defaults 815 mel frames / 300 tokens)")
+    ap.add_argument("--time-every", type=int, default=10, help="HIP-event pairs around the GEMM / attention launches on every N-th step of the timed region")
     ap.add_argument("--profile-ops", action="store_true", help="time every op family (adds event overhead; not for the headline number)")
     ap.add_argument("--backend", default=os.environ.get("UNAST_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) is the product path; gloo only rehearses the multi-rank logic on a 1-GPU box")
@@ -242,7 +243,7 @@ def main():
     sync()
     # HIP-event pairs around every GEMM / attention launch of a step cost ~15 ms of host time per step -- enough to make the host
     # the bottleneck (40 ms of enqueueing against 36 ms of GPU work) -- so they are on for every `every`-th step of the timed region.
-    every = 1 if (a.steps <= 4 or a.profile_ops) else 5
+    every = 1 if (a.steps <= 4 or a.profile_ops) else a.time_every
     n_timed = len(range(0, a.steps, every))
     with OpTimer(ops, timed) as ot:
         t0 = time.perf_counter()
@@ -318,7 +319,7 @@ def main():
                     "mfma_view": {"achieved_tflops": round(ach, 2), "frac_of_2500_dense_bf16": round(ach / PEAK_MFMA_BF16_TFLOPS, 4),
                                   "mfma_issue_tflops": round(ach * config.NSPLIT, 1), "sustained_mfma_peak_measured_tflops": SUSTAINED_MFMA_TFLOPS},
                     "note": "achieved = algorithmic bytes (fp32 A + B + C and epilogue operands, each once; conv inputs once, not per tap) / HIP-event "
-                            "time of these launches inside the timed region (event pairs on every 5th step when steps > 4, see timed_steps; text side, speech side and discriminator run on three HIP streams and the "
+                            "time of these launches inside the timed region (event pairs on every --time-every-th step when steps > 4, see timed_steps; text side, speech side and discriminator run on three HIP streams and the "
                             "speech side's weight gradients on a fourth, so a launch's duration includes time it shares the chip with kernels of the "
                             "others; `isolated` = the same launches in two extra single-stream steps after the timed region, comparable with profiles/); traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE per launch from "
                             "profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 passes of this command), null if that file is absent; mfma_view: 2MNK "
