@@ -72,7 +72,7 @@ def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bia
 
 
 import os as _os
-SPLITK_TARGET_BLOCKS = int(_os.environ.get("UNAST_SPLITK_TARGET", "320"))
+SPLITK_TARGET_BLOCKS = int(_os.environ.get("UNAST_SPLITK_TARGET", "256"))      # one workgroup per CU: 36.4 vs 36.8 ms/step at 320 (same box)
 SPLITK_MIN_KSTEPS = int(_os.environ.get("UNAST_SPLITK_MINK", "10"))
 
 
