@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
     int bx, bh;
     if (!xcd_remap((p.Tq + 127) / 128, p.B * p.H, bx, bh)) return;       // whole workgroup exits (EXEC stays full elsewhere)
+    if (p.causal) bx = (p.Tq + 127) / 128 - 1 - bx;                     // late query blocks see the most keys: dispatch them first
     const int h = bh % p.H, b = bh / p.H;
     const int qblk = bx * 128;
     const int q0 = qblk + wave * 32;
