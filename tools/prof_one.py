@@ -17,4 +17,13 @@ elif which == "attn_fwd":
     qkv = torch.randn(B * T, 3 * E, device=D); O = torch.empty(B * T, E, device=D); LSE = torch.empty(B, H, T, device=D)
     lens = torch.full((B,), T, dtype=torch.int32, device=D)
     for _ in range(10): ops.attn_fwd(qkv[:, :E], qkv[:, E:2*E], qkv[:, 2*E:], O, LSE, lens, B, H, T, T, False, drop_p=0.1, seed=1, stream_id=1)
+elif which == "attn_bwd":
+    B, H, T, E = 32, 4, 800, 256
+    qkv = torch.randn(B * T, 3 * E, device=D); O = torch.empty(B * T, E, device=D); LSE = torch.empty(B, H, T, device=D)
+    dO = torch.randn(B * T, E, device=D); dqkv = torch.empty(B * T, 3 * E, device=D); delta = torch.empty(B, H, T, device=D)
+    lens = torch.full((B,), T, dtype=torch.int32, device=D)
+    ops.attn_fwd(qkv[:, :E], qkv[:, E:2*E], qkv[:, 2*E:], O, LSE, lens, B, H, T, T, False, drop_p=0.1, seed=1, stream_id=1)
+    for _ in range(10):
+        ops.attn_bwd(qkv[:, :E], qkv[:, E:2*E], qkv[:, 2*E:], O, dO, LSE, delta, dqkv[:, :E], dqkv[:, E:2*E], dqkv[:, 2*E:], lens, B, H, T, T, False,
+                     drop_p=0.1, seed=1, stream_id=1)
 torch.cuda.synchronize()
