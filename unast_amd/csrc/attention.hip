@@ -16,7 +16,12 @@
 #include <type_traits>
 
 #define HD 64
-#define ALD 72                     // bf16 elements per LDS image row (64 + 8 pad) = 144 B
+#define ALD 64                     // bf16 elements per LDS image row = 128 B, 16-B chunks XOR-swizzled by (row & 6)
+// Byte offset of element (row, col) of a [rows][64] bf16 image.  The chunk swizzle makes both kinds of read conflict-free under
+// the hardware's lane groups (ds_read_b128: {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...; ds_read_b64_tr_b16: lanes 0-31 / 32-63):
+// with plain 144-B padded rows every ds_read_b128 fragment read was 2-way conflicting (SQ_LDS_BANK_CONFLICT = 36-44 % of the
+// LDS-active cycles, profiles/r01_pmc_attn_counters.txt) -- no row padding can be conflict-free for those groups.
+__device__ __forceinline__ int img_off(int row, int col) { return row * (ALD * 2) + ((((col >> 3) ^ (row & 6))) << 4) + ((col & 7) << 1); }
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 #define NEG_BIG (-1.0e30f)
@@ -52,13 +57,19 @@ __device__ __forceinline__ void pack_acc(const f32x4& a, const f32x4& b, bf16x8_
 
 // fragment [row = r0 + (lane&15)][k = 32*kst + 8g .. +7] of a [rows][ALD] image
 __device__ __forceinline__ bf16x8_t row_frag(const unsigned char* img, int r0, int kst, int l15, int g) {
-    return *reinterpret_cast<const bf16x8_t*>(img + ((r0 + l15) * ALD + 32 * kst + 8 * g) * 2);
+    // r0 is a multiple of 16: (row & 6) = (l15 & 6) and chunk 4*kst + g = (kst << 2) ^ g, so the swizzle term is one lane constant
+    const int sw = g ^ (l15 & 6);
+    return *reinterpret_cast<const bf16x8_t*>(img + (r0 + l15) * (ALD * 2) + (((kst << 2) ^ sw) << 4));
 }
 // transposed fragment: lane gets [col = c0 + (lane&15)][k-slots: rows k0+4g+0..3 then k0+16+4g+0..3]
 __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* img, int k0, int c0, int l15, int g) {
     const int q = l15 >> 2, p = l15 & 3;
-    s16x4 v0 = lds_read_tr16(img + ((k0 + 4 * g + q) * ALD + c0 + 4 * p) * 2);
-    s16x4 v1 = lds_read_tr16(img + ((k0 + 16 + 4 * g + q) * ALD + c0 + 4 * p) * 2);
+    // k0 and c0 are multiples of 16: row & 6 = (4g + q) & 6 for both rows, chunk = (c0 >> 3) ^ (p >> 1)
+    const int lane_off = (4 * g + q) * (ALD * 2) + ((p & 1) << 3);
+    const int sw = (p >> 1) ^ ((4 * g + q) & 6);
+    const unsigned char* base = img + k0 * (ALD * 2) + lane_off + ((((c0 >> 3) ^ sw)) << 4);
+    s16x4 v0 = lds_read_tr16(base);
+    s16x4 v1 = lds_read_tr16(base + 16 * (ALD * 2));
     s16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     return __builtin_bit_cast(bf16x8_t, v);
 }
@@ -90,8 +101,8 @@ __device__ __forceinline__ void tile_store(const float4 (&r)[NROWS / 16], unsign
         const int row = idx >> 4, dq = (idx & 15) * 4;
         u32x2 hi, lo;
         split4<NSPLIT>(r[i], hi, lo);
-        *reinterpret_cast<u32x2*>(hi_img + (row * ALD + dq) * 2) = hi;
-        if (NSPLIT == 3) *reinterpret_cast<u32x2*>(lo_img + (row * ALD + dq) * 2) = lo;
+        *reinterpret_cast<u32x2*>(hi_img + img_off(row, dq)) = hi;
+        if (NSPLIT == 3) *reinterpret_cast<u32x2*>(lo_img + img_off(row, dq)) = lo;
     }
 }
 
