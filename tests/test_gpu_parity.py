@@ -173,3 +173,53 @@ def test_ragged_batch_vs_oracle_b8():
         hot = n.startswith("text_m.prenet.") or n.startswith("text_m.encoder.transformer_encoder.layers.0.self_attn.in_proj")
         assert nrel < (2e-2 if hot else 5e-3), (n, nrel)
     assert np.median(errs) < 1e-3, np.median(errs)
+
+
+def test_one_token_and_one_frame_sequences_vs_oracle():
+    """The shortest inputs the collate contract allows next to full-length ones (a text of just EOS, a one-frame mel, a batch
+    whose padded tail dominates): forward, losses and gradients vs the pinned oracle."""
+    from collections import defaultdict
+    from oracle import unast_ref as R
+    from unast_amd import train
+    L = 2
+    args, model, opt, sd = build(L, 0.0)
+    g = torch.Generator().manual_seed(5)
+    B, Tt, Tm = 4, 9, 13
+    text_len = torch.tensor([9, 4, 2, 1])
+    mel_len = torch.tensor([13, 1, 6, 2])
+    text = torch.randint(3, 46, (B, Tt), generator=g)
+    mel = torch.rand(B, Tm, 80, generator=g)
+    for b in range(B):
+        text[b, text_len[b] - 1] = 2
+        text[b, text_len[b]:] = 0
+        mel[b, mel_len[b]:] = 0
+    batch = (text, mel, text_len, mel_len)
+    m = R.Model({k: v.clone() for k, v in sd.items()}, L)
+    for n, p in m.P.items():
+        if n.startswith("discriminator."):
+            p.requires_grad_(False)
+    ae = R.generator_losses(m, batch)
+    ae.pop("_ae_out")
+    (sum(ae.values()) / 2).backward()
+    sp = R.supervised_losses(m, batch)
+    (sum(sp.values()) / 2).backward()
+    losses = defaultdict(list)
+    model.train()
+    train.freeze_model_parameters(model.discriminator)
+    train.train_ae_step(losses, model, batch, 0, 2, args)
+    train.train_sp_step(losses, model, batch, 0, 2, args)
+    for k, v in list(ae.items()) + list(sp.items()):
+        assert np.isfinite(float(losses[k][0])) and abs(float(losses[k][0]) - v.item()) < 2e-4 * max(1.0, abs(v.item())), (k, float(losses[k][0]), v.item())
+    model.expose_grads()
+    tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.P.values() if p.grad is not None)))
+    errs = []
+    for n, p in model.named_parameters():
+        r = m.P[n].grad
+        if r is None:
+            assert p.grad is None, n
+            continue
+        assert torch.isfinite(p.grad).all(), n
+        if r.double().norm().item() < 1e-5 * tot:
+            continue
+        errs.append((p.grad.cpu().double() - r.double()).norm().item() / r.double().norm().item())
+    assert np.median(errs) < 1e-3 and max(errs) < 3e-2, (np.median(errs), max(errs))
