@@ -12,7 +12,7 @@ utils.set_seed(0); utils.set_deterministic(False)
 _, _, model, opt, sched = train.initialize_model(args)
 batch = tuple(torch.from_numpy(x).to(dev) for x in synth_batch(32, 180, 800, seed=0))
 batches = dict(unsup=[batch], sup=[batch], disc=[batch], cm=[]); losses = defaultdict(list)
-for i in range(4): train.train_step(losses, model, opt, sched, batches, i, args, defer_d_phase=True)
+for i in range(int(os.environ.get("WARM", "4"))): train.train_step(losses, model, opt, sched, batches, i, args, defer_d_phase=True)
 torch.cuda.synchronize()
 base = torch.cuda.Event(enable_timing=True); base.record()
 engine._Streams.trace = []

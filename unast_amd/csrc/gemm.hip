@@ -418,24 +418,47 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 ? 4 : 2)) void gemm_kernel(c
 // The remaining lever is fewer operand bytes per FLOP (wider tiles for N >= 512, fusing producer epilogues), not more
 // MFMA overlap.
 
-// C[m][n] (+)= sum_z slab[z][m][n]: reduction of the split-K partial slabs (plain streaming reads, deterministic order).
+// C[m][n] (+)= sum_z slab[z][m][n]: reduction of the split-K partial slabs (deterministic order).  64 float4 elements x 4 slab
+// groups per workgroup: a thread sums every 4th slab of its element with 8 loads in flight, the four partial sums meet in
+// LDS.  (One thread per element walking all slabs in a loop took 14 us for 64 slabs of 256 KB -- a chain of dependent
+// round trips from 64 workgroups; this form takes ~5.)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, size_t slab_stride, int ld_slab, int nsplit,
                                                             float* __restrict__ C, int ldc, int M, int N, int beta) {
+    __shared__ float4 part[4][64];
     const int nq = ld_slab >> 2;
     const size_t total = (size_t)M * nq;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int m = (int)(i / nq), n = (int)(i - (size_t)m * nq) * 4;
+    const int e = threadIdx.x & 63, zg = threadIdx.x >> 6;
+    for (size_t i0 = (size_t)blockIdx.x * 64; i0 < total; i0 += (size_t)gridDim.x * 64) {
+        const size_t i = i0 + e;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* sp = slab + (size_t)m * ld_slab + n;
-        for (int z = 0; z < nsplit; ++z) {
-            float4 v = *reinterpret_cast<const float4*>(sp + (size_t)z * slab_stride);
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        }
-        float* cp = C + (size_t)m * ldc + n;
-        const float av[4] = {a.x, a.y, a.z, a.w};
+        int m = 0, n = 0;
+        if (i < total) {
+            m = (int)(i / nq); n = (int)(i - (size_t)m * nq) * 4;
+            const float* sp = slab + (size_t)m * ld_slab + n;
+            int z = zg;
+            for (; z + 28 < nsplit; z += 32) {
+                float4 v[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n + r < N) cp[r] = beta ? cp[r] + av[r] : av[r];
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(sp + (size_t)(z + 4 * u) * slab_stride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+            }
+            for (; z < nsplit; z += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(sp + (size_t)z * slab_stride);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        }
+        part[zg][e] = a;
+        __syncthreads();
+        if (zg == 0 && i < total) {
+            const float4 b1 = part[1][e], b2 = part[2][e], b3 = part[3][e];
+            const float av[4] = {(a.x + b1.x) + (b2.x + b3.x), (a.y + b1.y) + (b2.y + b3.y), (a.z + b1.z) + (b2.z + b3.z), (a.w + b1.w) + (b2.w + b3.w)};
+            float* cp = C + (size_t)m * ldc + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < N) cp[r] = beta ? cp[r] + av[r] : av[r];
+        }
+        __syncthreads();
     }
 }
 
@@ -559,8 +582,8 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     else return unast_set_error(UNAST_ERR_ARG, "unast_gemm: unsupported operand mode pair (%d,%d)", a_mode, b_mode);
     if (p.slab) {
         size_t work = (size_t)M * (p.ld_slab / 4);
-        size_t blocks = (work + 255) / 256;
-        if (blocks > 1024) blocks = 1024;
+        size_t blocks = (work + 63) / 64;                  // 64 float4 elements per workgroup
+        if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p.slab, p.slab_stride, p.ld_slab, splitk, C, ldc, M, N, beta);
     }
     return unast_check_launch("unast_gemm");
