@@ -148,7 +148,17 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
     float a = 0.f;
     if (c < 2 * C) {
         const int which = c / C, col = c - which * C;
-        for (int b = ty; b < nblk; b += 16) a += part[((size_t)b * 2 + which) * C + col];
+        const float* pp = part + (size_t)which * C + col;
+        const size_t st = (size_t)2 * C;
+        int b = ty;
+        for (; b + 112 < nblk; b += 128) {                  // 8 loads in flight per thread (a plain loop is a chain of round trips)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(b + 16 * u) * st];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; b < nblk; b += 16) a += pp[(size_t)b * st];
     }
     red[ty][tx] = a;
     __syncthreads();
@@ -176,7 +186,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     float4 a = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     if (ty < nry) {
-        for (int r = r0 + ty; r < r1; r += nry) {
+        int r = r0 + ty;
+        for (; r + 3 * nry < r1; r += 4 * nry) {            // four rows in flight per thread
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (size_t)(r + u * nry) * ldx + tx * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
+                q.x += v[u].x * v[u].x; q.y += v[u].y * v[u].y; q.z += v[u].z * v[u].z; q.w += v[u].w * v[u].w;
+            }
+        }
+        for (; r < r1; r += nry) {
             float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + tx * 4);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
             q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
