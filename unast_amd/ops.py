@@ -126,16 +126,11 @@ def reset_wgrad_choices():
     _WGRAD_CHOICE.clear()
 
 
-_EXP_SKIP_WGRAD = _os.environ.get("UNAST_EXP_SKIP_WGRAD", "0") == "1"
-
-
 def _on_wgrad_stream(launch, tokens, key, *operands):
     """Runs `launch()` on the weight-gradient companion stream of the current stream (if any): that stream first waits for
     everything enqueued so far on the current one (the producers of dy / x), the operands are handed to the caching allocator
     with record_stream, and nobody waits for the result until the optimizer joins the streams.  All weight / bias gradient
     updates of a module come through here, so their read-modify-writes stay ordered on one stream."""
-    if _EXP_SKIP_WGRAD and tokens >= 8192:      # timing experiment only (wrong gradients): what is the speech-side weight-gradient work worth?
-        return None
     w = WGRAD_SIDE() if WGRAD_SIDE is not None else None
     if w is not None:
         off = _WGRAD_CHOICE.get(key)
