@@ -24,6 +24,8 @@ from collections import defaultdict
 
 import torch
 
+import unast_amd  # noqa: F401  (sets its HIP runtime defaults before the first device call)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
