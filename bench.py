@@ -24,10 +24,10 @@ from collections import defaultdict
 
 import torch
 
-import unast_amd  # noqa: F401  (sets its HIP runtime defaults before the first device call)
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+import unast_amd  # noqa: E402,F401  (sets its HIP runtime defaults before the first device call)
 
 # dense bf16 MFMA peak and HBM peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
 PEAK_MFMA_BF16_TFLOPS = 2500.0
