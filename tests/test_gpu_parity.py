@@ -223,3 +223,51 @@ def test_one_token_and_one_frame_sequences_vs_oracle():
             continue
         errs.append((p.grad.cpu().double() - r.double()).norm().item() / r.double().norm().item())
     assert np.median(errs) < 1e-3 and max(errs) < 3e-2, (np.median(errs), max(errs))
+
+
+def test_gradient_error_against_fp64_stays_within_the_documented_bounds():
+    """Gradients of the HIP path against an fp64 evaluation of the oracle (the fp32 reference has rounding noise of its own:
+    tools/oracle_fp64_noise.py).  Bounds = DESIGN.md section 3: median well below 1e-3; only the tensors upstream of the text
+    side's first self-attention (x16-scaled inputs, |score| ~ 300) may reach the 1e-2 range."""
+    from collections import defaultdict
+    from oracle import unast_ref as R
+    from unast_amd import train
+    from unast_amd.portable import synth_batch
+    L = 2
+    args, model, opt, sd = build(L, 0.0)
+    batch = tuple(torch.from_numpy(x) for x in synth_batch(4, 40, 120, seed=7, ragged=True))
+    orig_float = torch.Tensor.float
+    torch.Tensor.float = lambda self: self.double()
+    torch.set_default_dtype(torch.float64)
+    try:
+        m = R.Model({k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}, L)
+        for n, p in m.P.items():
+            if n.startswith("discriminator."):
+                p.requires_grad_(False)
+        b64 = (batch[0], batch[1].double(), batch[2], batch[3])
+        ae = R.generator_losses(m, b64)
+        ae.pop("_ae_out")
+        (sum(ae.values()) / 2).backward()
+        sp = R.supervised_losses(m, b64)
+        (sum(sp.values()) / 2).backward()
+        g64 = {n: p.grad.clone() for n, p in m.P.items() if p.grad is not None}
+    finally:
+        torch.Tensor.float = orig_float
+        torch.set_default_dtype(torch.float32)
+    losses = defaultdict(list)
+    model.train()
+    train.freeze_model_parameters(model.discriminator)
+    train.train_ae_step(losses, model, batch, 0, 2, args)
+    train.train_sp_step(losses, model, batch, 0, 2, args)
+    model.expose_grads()
+    tot = float(torch.sqrt(sum((g ** 2).sum() for g in g64.values())))
+    errs, hot_errs = [], []
+    for n, p in model.named_parameters():
+        if n not in g64 or g64[n].norm().item() < 1e-5 * tot:
+            continue
+        e = (p.grad.detach().double().cpu() - g64[n]).norm().item() / g64[n].norm().item()
+        hot = n.startswith("text_m.prenet.") or n.startswith("text_m.encoder.transformer_encoder.layers.0.")
+        (hot_errs if hot else errs).append((e, n))
+    assert np.median([e for e, _ in errs + hot_errs]) < 5e-4
+    assert max(errs)[0] < 5e-3, max(errs)
+    assert max(hot_errs)[0] < 3e-2, max(hot_errs)
