@@ -47,6 +47,16 @@ def grads(scope):
 
     def text_encode(self, text, text_len):
         prev = state["on"]
+        if scope == "text-prenet":          # the three convolutions in front of the encoder stack only
+            P = self.P
+            x = self._embed(text)
+            state["on"] = True
+            for i in (1, 2, 3):
+                x = R.conv1d_k5(x, P["text_m.prenet.conv%d.conv.weight" % i], P["text_m.prenet.conv%d.conv.bias" % i], 2)
+                x = torch.relu(self._bn(x, "text_m.prenet.batch_norm%d." % i))
+            state["on"] = prev
+            x = R.pos_enc(x, self.buf["text_m.pos_emb.pe"])
+            return R.encoder_stack(x, text_len, P, "text_m.encoder.transformer_encoder.layers.", self.L, self.nhead)
         state["on"] = prev or scope == "text-encoder"
         try:
             return orig_enc(self, text, text_len)
@@ -72,7 +82,7 @@ ref = grads("none")
 watch = ["text_m.prenet.embed.weight", "text_m.prenet.conv1.conv.weight", "text_m.prenet.batch_norm3.weight",
          "text_m.encoder.transformer_encoder.layers.0.self_attn.in_proj_weight", "text_m.encoder.transformer_encoder.layers.0.linear1.weight",
          "text_m.encoder.transformer_encoder.layers.1.self_attn.in_proj_weight", "speech_m.encoder.transformer_encoder.layers.0.self_attn.in_proj_weight"]
-for scope in ("text-enc-l0-attn", "text-encoder", "everything"):
+for scope in (sys.argv[1:] or ["text-prenet", "text-enc-l0-attn", "text-encoder", "everything"]):
     g = grads(scope)
     print("split-bf16 operands emulated in the forward of: %s" % scope)
     for n in watch:
