@@ -197,7 +197,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or (os.environ.get("UNAST_DDP_FORCE", "0") == "1" and "RANK" in os.environ)     # forced: rehearsal of the RCCL path with one rank
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
@@ -230,7 +231,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize(dev)
@@ -339,7 +340,7 @@ def main():
            "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16x3" if config.NSPLIT == 3 else "bf16", "data": "synthetic",
-           "dist_backend": (a.backend if world > 1 else None),
+           "dist_backend": (a.backend if dist_on else None),
            "config": {"workload": "%s: full adversarial gen+disc train step (AE+SP+clip/AdamW, D step+clip/AdamW), per-GPU B=%d, T_text=%d, T_mel=%d, "
                                   "num_layers=%d, d=256, 4 heads, FFN 1024, 2x bi-LSTM(64) discriminator, dropout/noise/SpecAugment active%s" % (
                                       a.workload, B, Tt, Tm, L, (" + %d cross-model sub-step(s) with K/V-cached generation (NOT the headline configuration)" % a.cm_steps) if a.cm_steps else ""),

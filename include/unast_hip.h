@@ -210,13 +210,17 @@ int unast_leaky_dropout(const float* x, const float* dy, float* out, int rows, i
  * Blocking (hipMemcpyToSymbol); call it while no kernel of this library is in flight. */
 int unast_set_rng_epoch(const unsigned int* counter);
 
-/* optimizer_step (src/train.py:358-363): clip_grad_norm_ + torch.optim.AdamW over flat fp32 buffers.
+/* optimizer_step (src/train.py:358-363): clip_grad_norm_ + torch.optim.AdamW (decoupled = 1) or torch.optim.Adam with L2
+ * weight decay (decoupled = 0; optim_type 'adam', src/train.py:929-930) over flat fp32 buffers.
+ * dev_hyper (may be NULL): three floats in device memory {lr, 1 - beta1^t, sqrt(1 - beta2^t)} that replace lr / step, so a
+ * captured HIP graph of the step replays with the current schedule values.
  * split_out (may be NULL; needs n % 4 == 0): the updated parameters once more in the GEMM's pre-split operand format --
  * per 4 consecutive elements one 16-byte chunk [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] of bf16, hi = RNE(x), lo = RNE(x - hi).
  * unast_split_f32 produces the same format from any fp32 buffer (model load, load_state_dict). */
 int unast_sumsq(const float* g, int64_t n, double* out, hipStream_t stream);
 int unast_adamw(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
-                float beta1, float beta2, float eps, float weight_decay, int step, float* split_out, hipStream_t stream);
+                float beta1, float beta2, float eps, float weight_decay, int step, float* split_out, int decoupled,
+                const float* dev_hyper, hipStream_t stream);
 int unast_split_f32(const float* src, float* dst, int64_t n, hipStream_t stream);
 
 #ifdef __cplusplus

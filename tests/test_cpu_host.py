@@ -148,6 +148,72 @@ def test_gradient_exchange_two_ranks_gloo(tmp_path):
     assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]
 
 
+_BUCKET_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from unast_amd import ddp
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ddp._State.scale_fn = lambda buf, a: buf.mul_(a)
+class P:
+    def __init__(self, n): self.n = n
+    def numel(self): return self.n
+class St: pass
+st = St()
+# flat layout as engine.FlatStore builds it: generator buckets in state_dict order, then the discriminator, then reduce_c_W
+names = [("text_m.prenet.embed.weight", 100), ("text_m.encoder.l0.w", 156), ("text_m.decoder.l0.w", 200), ("text_m.postnet.fc1.weight", 56),
+         ("speech_m.prenet.fc1.w", 64), ("speech_m.encoder.l0.w", 128), ("speech_m.decoder.l0.w", 192), ("speech_m.postnet.conv1.w", 64),
+         ("discriminator.fc2.weight", 64)]
+st.offsets, st.params, off = {}, {}, 0
+for n, k in names:
+    st.offsets[n] = off; st.params[n] = P(k); off += k
+st.regions = {"gen": (0, 960), "disc": (960, 1024)}
+st.grad = torch.arange(1024, dtype=torch.float32) * (rank + 1)
+st.touched = {"gen"}
+br = ddp.bucket_ranges(st)
+assert br == {"text_enc": (0, 256), "text_dec": (256, 512), "speech_enc": (512, 704), "speech_dec": (704, 960)}, br
+exp = torch.arange(1024, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+own = torch.arange(1024, dtype=torch.float32) * (rank + 1)
+# --- generator phase: armed in the last sub-step; the speech encoder is used by two calls (both must finish first) ---
+ddp.segment_backward("text_dec", st)                     # not armed yet (an earlier sub-step): nothing may travel
+assert ddp._State.log == []
+ddp.arm()
+for b in ("text_enc", "speech_enc", "speech_enc", "speech_dec", "text_dec"):
+    ddp.segment_forward(b)
+ddp.segment_backward("text_dec", st)
+assert [l[0] for l in ddp._State.log] == ["text_dec"] and torch.allclose(st.grad[256:512], exp[256:512])
+assert torch.equal(st.grad[:256], own[:256]) and torch.equal(st.grad[512:], own[512:])       # everything else still local
+ddp.segment_backward("speech_dec", st)
+ddp.segment_backward("speech_enc", st)                   # first of two users: not final yet
+assert [l[0] for l in ddp._State.log] == ["text_dec", "speech_dec"]
+ddp.segment_backward("speech_enc", st)
+assert [l[0] for l in ddp._State.log] == ["text_dec", "speech_dec", "speech_enc"]
+n = ddp.finish(st, [(0, 960)])                            # text_enc never signalled: the optimizer side reduces the remainder
+assert n == 1 and ddp._State.log[-1] == ("rest", 0, 256)
+assert torch.allclose(st.grad[:960], exp[:960]) and torch.equal(st.grad[960:], own[960:])    # each element reduced exactly once
+# --- discriminator phase: nothing pre-issued, one collective over its range ---
+st.touched = {"disc"}
+n = ddp.finish(st, [(960, 1024)])
+assert n == 1 and torch.allclose(st.grad, exp)
+assert not ddp._State.armed and ddp._State.issued == []
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_bucketed_gradient_exchange_two_ranks_gloo(tmp_path):
+    """unast_amd.ddp: buckets travel when (and only when) their last backward of the armed sub-step has been enqueued, every
+    gradient element is reduced exactly once per optimizer phase, and what the hooks did not see is reduced by finish()."""
+    script = tmp_path / "w.py"
+    script.write_text(_BUCKET_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29535", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]
+
+
 def test_golden_fixtures_are_data_only(golden_dir):
     for f in os.listdir(golden_dir):
         assert f.endswith(".npz"), f

@@ -59,9 +59,10 @@ def test_gemm_full_size_linearity_and_row_samples():
     assert relerr(dx[rows], dyf[rows].double().cpu() @ W.double().cpu()) < 3e-5
 
 
-@pytest.mark.parametrize("Tq,Tk,causal", [(TM, TM, True), (TM, TM, False), (TM, TT, False), (TT, TM, False)])
+@pytest.mark.parametrize("Tq,Tk,causal", [(TM, TM, True), (TM, TM, False), (TM, TT, False), (TT, TM, False),
+                                          (2000, 2000, True), (2000, 2000, False), (2000, 300, False), (300, 2000, False)])
 def test_attention_full_size_properties(Tq, Tk, causal):
-    """The four (Tq,Tk) shapes of config 3 with ragged key lengths: softmax rows sum to one (V = 1 -> O = 1), linearity in V,
+    """The four (Tq,Tk) shapes of config 3 and of config 5 (T_mel=2000, T_text=300) with ragged key lengths: softmax rows sum to one (V = 1 -> O = 1), linearity in V,
     sampled (batch, head) slices against fp64, masked keys receive exactly zero gradient, dO = 0 -> all gradients zero."""
     from unast_amd import ops
     g = torch.Generator().manual_seed(Tq + Tk)
@@ -117,12 +118,13 @@ def test_attention_full_size_properties(Tq, Tk, causal):
     assert float(dq.abs().max()) == 0.0 and float(dk.abs().max()) == 0.0 and float(dv.abs().max()) == 0.0
 
 
-def test_lstm_full_size_properties():
-    """Discriminator batch of config 3 (64 sequences x 800 steps, ragged): padded steps stay zero, the reverse direction equals
+@pytest.mark.parametrize("T", [TM, 2000])
+def test_lstm_full_size_properties(T):
+    """Discriminator batch of config 3 (64 sequences x 800 steps, ragged) and of config 5 (x 2000 steps): padded steps stay zero, the reverse direction equals
     the forward direction run on the time-reversed sequence, and a sampled sequence matches torch's fp64 LSTM."""
     from unast_amd import ops
     g = torch.Generator().manual_seed(11)
-    Bd, T, Hh = 2 * B, TM, 64
+    Bd, Hh = 2 * B, 64
     lens = torch.randint(T // 4, T + 1, (Bd,), generator=g); lens[0] = T; lens[1] = 1
     li = lens.to(torch.int32).to(D)
     lstm = torch.nn.LSTM(128, Hh, num_layers=1, bidirectional=True, batch_first=True).double()

@@ -317,6 +317,31 @@ def test_adamw_matches_oracle():
         assert relerr(p, pr["w"].detach()) < 1e-6
 
 
+def test_adam_l2_form_and_device_hyper_parameters():
+    """optim_type 'adam' (src/train.py:929-930: torch.optim.Adam, weight decay added to the gradient) against torch's own
+    Adam in fp64 behind clip_grad_norm_, and the device-resident {lr, 1-b1^t, sqrt(1-b2^t)} block a captured step reads."""
+    from unast_amd import ops
+    g = torch.Generator().manual_seed(10)
+    n = 4099
+    p0 = torch.randn(n, generator=g); grads = [torch.randn(n, generator=g) * s for s in (2.0, 0.05, 1.0)]
+    ref = torch.nn.Parameter(p0.double().clone())
+    opt = torch.optim.Adam([ref], lr=2e-3, weight_decay=1e-2)
+    p = p0.to(D).clone(); m = torch.zeros(n, device=D); v = torch.zeros(n, device=D)
+    p2 = p.clone(); m2 = m.clone(); v2 = v.clone()
+    ss = torch.zeros(1, dtype=torch.float64, device=D)
+    hyper = torch.zeros(3, device=D)
+    for step, gr in enumerate(grads, 1):
+        ref.grad = gr.double().clone()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        ss.zero_(); ops.sumsq(gr.to(D), ss)
+        ops.adamw(p, gr.to(D), m, v, ss, 1.0, 2e-3, 0.9, 0.999, 1e-8, 1e-2, step, decoupled=False)
+        assert relerr(p, ref.detach()) < 2e-6, step
+        hyper.copy_(torch.tensor([2e-3, 1 - 0.9 ** step, math.sqrt(1 - 0.999 ** step)]))
+        ops.adamw(p2, gr.to(D), m2, v2, ss, 1.0, 123.0, 0.9, 0.999, 1e-8, 1e-2, 0, decoupled=False, dev_hyper=hyper)
+        assert torch.equal(p2, p) and torch.equal(m2, m) and torch.equal(v2, v), step
+
+
 def test_specaugment_spans():
     from unast_amd import ops
     B, T, M = 4, 300, 80

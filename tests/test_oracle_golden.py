@@ -124,6 +124,54 @@ def test_full_step_matches_reference(golden_dir, name):
         assert np.array_equal(dd == 0, tot == 0), "set of untouched parameters differs (reduce_c_W must not move)"
 
 
+def test_generator_only_step_matches_reference(golden_dir):
+    """BASELINE.json config 2's branch (num_layers=3, use_discriminator=False: src/train.py:365-416 `else` arms, no D phase):
+    outputs, the four losses, gradients and AdamW deltas of the oracle against the reference-generated fixture."""
+    g = load(golden_dir, "step_b3_t20_m56_l3_nodisc")
+    B, Tt, Tm, L, ragged = [int(v) for v in g["meta"]]
+    assert L == 3 and "loss/d" not in g.files and "loss/d_ae" not in g.files
+    from unast_amd.spec import state_dict_spec
+    sd = {k: portable_tensor(k, shp, 1234) for k, shp in state_dict_spec(L, use_discriminator=False).items()}
+    names = [str(n) for n in g["param_names"]]
+    assert [k for k in sd if k in set(names)] == names and not any(n.startswith("discriminator.") for n in names)
+    batch = tuple(torch.from_numpy(g[k]) for k in ("text", "mel", "text_len", "mel_len"))
+    m = R.Model(sd, L, requires_grad=False)
+    m.update_bn = False
+    with torch.no_grad():
+        text, mel, tl, ml = batch
+        logits, t_enc = m.text_ae(text, tl)
+        pre, post, stop, s_enc = m.speech_ae(mel, ml)
+        pre2, post2, stop2, _ = m.tts(text, tl, mel, ml)
+        logits2, _ = m.asr(text, tl, mel, ml)
+    for got, key in ((logits, "ae_logits"), (t_enc, "ae_t_enc"), (pre, "ae_pre"), (post, "ae_post"), (stop, "ae_stop"),
+                     (s_enc, "ae_s_enc"), (pre2, "tts_pre"), (post2, "tts_post"), (stop2, "tts_stop"), (logits2, "asr_logits")):
+        assert rel(got.numpy(), g[key]) < 5e-5, key      # fp32 accumulation-order noise of the x16-scaled text side: 2.4e-5
+    m = R.Model(sd, L)
+    opt = R.AdamW(m.P, lr=float(g["lr"]), weight_decay=1e-6)
+    grads = {}
+    orig_step = opt.step
+
+    def spy(clip):
+        grads[len(grads)] = {n: (p.grad.clone() if p.grad is not None else None) for n, p in m.P.items()}
+        return orig_step(clip)
+    opt.step = spy
+    before = {n: p.detach().clone() for n, p in m.P.items()}
+    rec = R.full_step(m, opt, batch, use_discriminator=False)
+    assert sorted(k for k in rec if not k.endswith("norm")) == ["asr_", "s_ae", "t_ae", "tts_"] and len(grads) == 1
+    for k in ["t_ae", "s_ae", "asr_", "tts_"]:
+        assert abs(rec[k] - g["loss/" + k]) < 5e-6 * max(1.0, abs(g["loss/" + k])), (k, rec[k], g["loss/" + k])
+    assert abs(rec["gen_grad_norm"] - g["gen_grad_norm"]) < 2e-4 * g["gen_grad_norm"]
+    gn = np.array([grads[0][n].double().norm().item() if grads[0][n] is not None else -1.0 for n in names])
+    assert np.array_equal(gn < 0, g["gen_grad_norms"] < 0)
+    assert np.allclose(gn, g["gen_grad_norms"], rtol=2e-3, atol=1e-6 * g["gen_grad_norm"])
+    for key in g.files:
+        if key.startswith("gen_grad/"):
+            assert np.abs(grads[0][key[len("gen_grad/"):]].numpy() - g[key]).max() < 5e-4 * np.abs(g[key]).max() + 1e-6, key
+    dd = np.array([(m.P[n].detach() - before[n]).double().norm().item() for n in names])
+    well = g["gen_grad_norms"] > 1e-4 * g["gen_grad_norm"]
+    assert np.allclose(dd[well], g["gen_delta_norms"][well], rtol=1e-2, atol=1e-7)
+
+
 def test_packed_lstm_form_equals_time_loop():
     """The oracle's two forms of the LSTM discriminator (explicit loop / torch packed-sequence LSTM) agree, values and grads."""
     torch.manual_seed(1)

@@ -72,9 +72,12 @@ def deterministic_mode(model, network, train):
     train.torch.randperm = lambda n, *a, **k: torch.arange(n)
 
 
-def run_case(mods, name, B, Tt, Tm, L, ragged, out_dir, lr_warm_steps):
+def run_case(mods, name, B, Tt, Tm, L, ragged, out_dir, lr_warm_steps, use_discriminator=True):
+    """use_discriminator=False is BASELINE.json config 2's branch (src/train.py:922-924 builds no discriminator, the
+    `else` arms of train_ae_step / train_sp_step src/train.py:365-416 run, the D phase is skipped src/train.py:631-638)."""
     module, network, utils, train = mods
     args = make_args(L)
+    args.use_discriminator = use_discriminator
     train.DEVICE = torch.device("cpu")
     train.WRITER = None
     utils.set_seed(0)
@@ -115,7 +118,8 @@ def run_case(mods, name, B, Tt, Tm, L, ragged, out_dir, lr_warm_steps):
 
     # ---- generator phase ----
     losses = collections.defaultdict(list)
-    train.freeze_model_parameters(model.discriminator)
+    if use_discriminator:
+        train.freeze_model_parameters(model.discriminator)
     train.train_ae_step(losses, model, batch, 0, 2, args)
     train.train_sp_step(losses, model, batch, 0, 2, args)
     grads = {n: (p.grad.detach().clone() if p.grad is not None else None)
@@ -143,24 +147,27 @@ def run_case(mods, name, B, Tt, Tm, L, ragged, out_dir, lr_warm_steps):
         out["gen_delta/" + n] = (after[n] - before[n]).numpy()
 
     # ---- discriminator phase ----
-    train.unfreeze_model_parameters(model.discriminator)
-    train.train_discriminator_step(losses, model, batch, 0, 1, args)
-    dgrads = {n: (p.grad.detach().clone() if p.grad is not None else None)
-              for n, p in model.named_parameters()}
-    dnorm = torch.sqrt(sum((g.double() ** 2).sum() for g in dgrads.values() if g is not None))
-    out["d_grad_norm"] = np.float64(dnorm.item())
-    out["d_grad_norms"] = np.array([dgrads[n].double().norm().item() if dgrads[n] is not None else -1.0
-                                    for n in names])
-    for n in ["discriminator.fc2.weight", "discriminator.rnn.reduce_h_W.bias",
-              "discriminator.rnn.rnn.bias_hh_l1_reverse", "discriminator.rnn.rnn.bias_ih_l0"]:
-        out["d_grad/" + n] = dgrads[n].numpy()
-    before = after
-    train.optimizer_step(model, opt, args)
-    after = {n: p.detach().clone() for n, p in model.named_parameters()}
-    out["d_delta_norms"] = np.array([(after[n] - before[n]).double().norm().item() for n in names])
+    dnorm = torch.zeros(())
+    if use_discriminator:
+        train.unfreeze_model_parameters(model.discriminator)
+        train.train_discriminator_step(losses, model, batch, 0, 1, args)
+        dgrads = {n: (p.grad.detach().clone() if p.grad is not None else None)
+                  for n, p in model.named_parameters()}
+        dnorm = torch.sqrt(sum((g.double() ** 2).sum() for g in dgrads.values() if g is not None))
+        out["d_grad_norm"] = np.float64(dnorm.item())
+        out["d_grad_norms"] = np.array([dgrads[n].double().norm().item() if dgrads[n] is not None else -1.0
+                                        for n in names])
+        for n in ["discriminator.fc2.weight", "discriminator.rnn.reduce_h_W.bias",
+                  "discriminator.rnn.rnn.bias_hh_l1_reverse", "discriminator.rnn.rnn.bias_ih_l0"]:
+            out["d_grad/" + n] = dgrads[n].numpy()
+        before = after
+        train.optimizer_step(model, opt, args)
+        after = {n: p.detach().clone() for n, p in model.named_parameters()}
+        out["d_delta_norms"] = np.array([(after[n] - before[n]).double().norm().item() for n in names])
 
-    for k in ["t_ae", "s_ae", "d_ae", "asr_", "tts_", "sp_d", "d"]:
+    for k in (["t_ae", "s_ae", "d_ae", "asr_", "tts_", "sp_d", "d"] if use_discriminator else ["t_ae", "s_ae", "asr_", "tts_"]):
         out["loss/" + k] = np.float64(losses[k][0])
+    assert sorted(losses.keys()) == sorted(k[5:] for k in out if k.startswith("loss/"))
     fsd = model.state_dict()
     for k, v in fsd.items():
         if "running_" in k:
@@ -240,10 +247,16 @@ def unit_vectors(mods, out_dir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
+    ap.add_argument("--only", default=None, help="generate just this case (name of the .npz without extension)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
     mods = import_reference()
+    # BASELINE.json config 2's branch at fixture size: 3 layers, no discriminator (generator-only AE + SP + optimizer step)
+    if a.only in (None, "step_b3_t20_m56_l3_nodisc"):
+        run_case(mods, "step_b3_t20_m56_l3_nodisc", 3, 20, 56, 3, True, a.out, lr_warm_steps=2000, use_discriminator=False)
+    if a.only is not None:
+        return
     unit_vectors(mods, a.out)
     # config 1 of BASELINE.json (1 utterance, Tt=40, Tm=200, L=4), LR at schedule peak
     run_case(mods, "step_b1_t40_m200_l4", 1, 40, 200, 4, False, a.out, lr_warm_steps=2000)

@@ -531,7 +531,7 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     // tile width: 128x256 when N is wide enough and the grid still fills the chip; `tile_wn` (2/4) overrides, 0 = auto
     int wn = tile_wn;
     if (wn != 2 && wn != 4 && wn != 8) {
-        // measured on MI355X (tools/bench_gemm2.py): for forward / dgrad shapes the 128x128 tile shared by 8 waves
+        // measured on MI355X (tools/bench_gemm.py): for forward / dgrad shapes the 128x128 tile shared by 8 waves
         // (<=128 VGPRs, 4 waves/SIMD) is 10-25 % faster than 4 waves (more waves to cover LDS/barrier/global latencies);
         // weight gradients (long K, split-K) are equal, the 128x256 tile only helps isolated large shapes.
         wn = (a_mode == OP_RC) ? 2 : 8;

@@ -1,7 +1,10 @@
-// Fused gradient-clip + AdamW over flat parameter/gradient buffers (src/train.py:358-363, 929-932).
+// Fused gradient-clip + Adam / AdamW over flat parameter/gradient buffers (src/train.py:358-363, 929-932).
 // Two launches per optimizer phase: (1) sum of squares of the active gradient ranges -> double scalar,
 // (2) one pass that applies clip_grad_norm_'s coefficient and the torch.optim.AdamW update
-//     p *= 1-lr*wd ; m = lerp(m,g,1-b1) ; v = b2*v + (1-b2) g^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).
+//     p *= 1-lr*wd ; m = lerp(m,g,1-b1) ; v = b2*v + (1-b2) g^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+//     (optim_type 'adam', src/train.py:929-930: no decay factor, g += wd * p instead -- torch.optim.Adam's L2 form).
+// The step-dependent scalars (lr, 1-b1^t, sqrt(1-b2^t)) come by value or from three floats in device memory, so that a
+// captured HIP graph of the train step replays with the current learning rate and bias corrections.
 // HBM-bound: 4 streams read (p,g,m,v) + 3 written (p,m,v), 16 B per lane.
 #include "common.h"
 
@@ -25,16 +28,19 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // format -- per 4 consecutive elements one 16-B chunk [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] of bf16 (same byte offsets as fp32).
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     size_t n4, size_t n, const double* __restrict__ sumsq, float max_norm, float lr, float b1, float b2,
-                                                    float eps, float wd, float bc1, float bc2_sqrt, float* __restrict__ split_out) {
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float* __restrict__ split_out,
+                                                    int decoupled, const float* __restrict__ dev_hyper) {
+    if (dev_hyper) { lr = dev_hyper[0]; bc1 = dev_hyper[1]; bc2_sqrt = dev_hyper[2]; }
     float coef = 1.f;
     if (max_norm > 0.f) {
         const float total = (float)sqrt(sumsq[0]);
         coef = fminf(max_norm / (total + 1e-6f), 1.f);
     }
-    const float decay = 1.f - lr * wd;
+    const float decay = decoupled ? 1.f - lr * wd : 1.f;
+    const float l2 = decoupled ? 0.f : wd;
     const float step = lr / bc1;
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
-        gg *= coef;
+        gg = gg * coef + l2 * pp;
         pp *= decay;
         mm = mm + (gg - mm) * (1.f - b1);
         vv = vv * b2 + (1.f - b2) * gg * gg;
@@ -73,8 +79,10 @@ extern "C" int unast_sumsq(const float* g, int64_t n, double* out, hipStream_t s
 }
 
 extern "C" int unast_adamw(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
-                           float beta1, float beta2, float eps, float weight_decay, int step, float* split_out, hipStream_t stream) {
-    UNAST_REQUIRE(p && g && m && v && n > 0 && step >= 1, "unast_adamw: bad arguments");
+                           float beta1, float beta2, float eps, float weight_decay, int step, float* split_out, int decoupled,
+                           const float* dev_hyper, hipStream_t stream) {
+    UNAST_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || dev_hyper), "unast_adamw: bad arguments");
+    if (step < 1) step = 1;
     UNAST_REQUIRE(!(max_norm > 0.f) || sumsq, "unast_adamw: clipping needs the sum-of-squares scalar");
     UNAST_REQUIRE(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0, "unast_adamw: buffers must be 16-byte aligned");
     UNAST_REQUIRE(!split_out || ((((uintptr_t)split_out) & 15) == 0 && (n & 3) == 0), "unast_adamw: split_out needs 16-byte alignment and n %% 4 == 0");
@@ -84,7 +92,7 @@ extern "C" int unast_adamw(float* p, const float* g, float* m, float* v, int64_t
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, (size_t)n / 4, (size_t)n, sumsq, max_norm, lr, beta1,
-                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), split_out);
+                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), split_out, decoupled, dev_hyper);
     return unast_check_launch("unast_adamw");
 }
 

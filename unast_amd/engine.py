@@ -211,6 +211,9 @@ class _Segment(torch.autograd.Function):
         in_vars = [Var(t) if isinstance(t, torch.Tensor) and t.is_floating_point() else t for t in inputs]
         outs = run(tape, *in_vars)
         ctx.tape, ctx.in_vars, ctx.out_vars = tape, in_vars, outs
+        ctx.hook = hook
+        if hook is not None:
+            hook[0](hook[1])                           # ddp.segment_forward(bucket)
         ctx.label = getattr(run, "__qualname__", "segment").split(".<locals>")[0]
         res = tuple(o.v for o in outs)
         return res if len(res) > 1 else res[0]
@@ -241,13 +244,22 @@ class _Segment(torch.autograd.Function):
                 g.record_stream(cur)                  # may have been produced (and be freed) on another stream
             o.g = g
         ctx.tape.backward()
+        if ctx.hook is not None:
+            ctx.hook[2](ctx.hook[1], ctx.hook[3])      # ddp.segment_backward(bucket, store): this call's gradients are enqueued
         grads = tuple((v.g if isinstance(v, Var) else None) for v in ctx.in_vars)
         ctx.tape = ctx.in_vars = ctx.out_vars = None
         return (None, None) + grads
 
 
+def ddp_hook(bucket, store):
+    """`hook` argument of run_segment for a public call whose parameters form the gradient bucket `bucket` (unast_amd.ddp)."""
+    from . import ddp
+    return (ddp.segment_forward, bucket, ddp.segment_backward, store)
+
+
 def run_segment(run, hook, *inputs):
-    """Executes `run(tape, *vars) -> [Var,...]`.  With grad mode off no tape is kept."""
+    """Executes `run(tape, *vars) -> [Var,...]`.  With grad mode off no tape is kept.  `hook` (see ddp_hook) tells the
+    data-parallel layer when this call's backward has been enqueued."""
     if not torch.is_grad_enabled():
         in_vars = [Var(t) if isinstance(t, torch.Tensor) and t.is_floating_point() else t for t in inputs]
         outs = run(None, *in_vars)

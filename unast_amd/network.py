@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import functional as F
 from . import ops
-from .engine import Var, acc, run_segment, FlatStore, on_stream
+from .engine import Var, acc, run_segment, FlatStore, on_stream, ddp_hook
 from .module import (SpeechPrenet, SpeechPostnet, TextPrenet, TextPostnet, PositionalEncoding, TransformerEncoder,
                      TransformerDecoder, RNNEncoder)
 from .spec import state_dict_spec  # noqa: F401  (re-export)
@@ -136,7 +136,7 @@ class TextTransformer(AutoEncoderNet):
 
         def run(tape, dummy):
             return [_out3d(tape, F.text_encode(cx, tape, self, ids, lens, noise_in), B, T)]
-        enc = run_segment(run, None, cx.st.dummy)
+        enc = run_segment(run, ddp_hook("text_enc", cx.st), cx.st.dummy)
         return enc, (None, lens)
 
     @on_stream("text")
@@ -160,7 +160,7 @@ class TextTransformer(AutoEncoderNet):
                         out.g = _as_padded(o.g, B * T, ldl, V)
                 tape.record(bwd)                                                    # recorded last => runs first
             return [o]
-        return run_segment(run, None, cx.st.dummy, enc_outputs)
+        return run_segment(run, ddp_hook("text_dec", cx.st), cx.st.dummy, enc_outputs)
 
     def postprocess(self, out):
         raise NotImplementedError("use decode_sequence(); the text post-net is fused into it")
@@ -211,7 +211,7 @@ class SpeechTransformer(AutoEncoderNet):
 
         def run(tape, dummy):
             return [_out3d(tape, F.speech_encode(cx, tape, self, mel, lens, noise_in), B, T)]
-        enc = run_segment(run, None, cx.st.dummy)
+        enc = run_segment(run, ddp_hook("speech_enc", cx.st), cx.st.dummy)
         return enc, (None, lens)
 
     @on_stream("speech")
@@ -248,7 +248,7 @@ class SpeechTransformer(AutoEncoderNet):
                         head.g = buf
                 tape.record(bwd)                                                    # runs first
             return [o_pre, o_post, o_stop]
-        pre, post, stop = run_segment(run, None, cx.st.dummy, enc_outputs)
+        pre, post, stop = run_segment(run, ddp_hook("speech_dec", cx.st), cx.st.dummy, enc_outputs)
         return pre, post, stop, tgt_lens
 
     def postprocess(self, out):

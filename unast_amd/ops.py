@@ -428,9 +428,10 @@ def sumsq(g, out):
     check(lib().unast_sumsq(_p(g), g.numel(), _p(out), _stream()), "unast_sumsq")
 
 
-def adamw(p, g, m, v, sumsq_scalar, max_norm, lr, beta1, beta2, eps, wd, step, split_out=None):
+def adamw(p, g, m, v, sumsq_scalar, max_norm, lr, beta1, beta2, eps, wd, step, split_out=None, decoupled=True, dev_hyper=None):
+    """dev_hyper: float32 [3] device tensor {lr, 1 - beta1^t, sqrt(1 - beta2^t)} read by the kernel instead of lr / step."""
     check(lib().unast_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq_scalar), max_norm, lr, beta1, beta2, eps, wd, step,
-                            _p(split_out), _stream()), "unast_adamw")
+                            _p(split_out), int(bool(decoupled)), _p(dev_hyper), _stream()), "unast_adamw")
 
 
 def split_f32(src, dst):

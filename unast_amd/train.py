@@ -23,7 +23,7 @@ from collections import defaultdict
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ddp, ops
 from .engine import Var, run_segment, on_stream, side_streams, join_streams, stream_of, join_wgrad_streams
 from .network import TextTransformer, SpeechTransformer, UNAST, Discriminator, LSTMDiscriminator, _as_padded
 from .utils import (PAD_IDX, SOS_IDX, EOS_IDX, lens_i32, specaugment, sent_lens_to_mask, get_teacher_ratio, is_deterministic,
@@ -448,12 +448,13 @@ def train_step(losses, model, optimizer, scheduler, batches, step, args, defer_d
     if args.use_discriminator:
         freeze_model_parameters(model.discriminator)
     accum_steps = args.ae_steps + getattr(args, "cm_steps", 0) + args.sp_steps
-    for si in range(args.ae_steps):
-        train_ae_step(losses, model, batches["unsup"][si], step, accum_steps, args)
-    for si in range(getattr(args, "cm_steps", 0)):
-        train_cm_step(losses, model, batches["cm"][si], step, accum_steps, args)
-    for si in range(args.sp_steps):
-        train_sp_step(losses, model, batches["sup"][si], step, accum_steps, args)
+    subs = [(train_ae_step, batches["unsup"][si]) for si in range(args.ae_steps)]
+    subs += [(train_cm_step, batches["cm"][si]) for si in range(getattr(args, "cm_steps", 0))]
+    subs += [(train_sp_step, batches["sup"][si]) for si in range(args.sp_steps)]
+    for i, (fn, b) in enumerate(subs):
+        if i == len(subs) - 1:
+            ddp.arm()          # gradients become final in this sub-step: buckets travel as soon as their backward is enqueued
+        fn(losses, model, b, step, accum_steps, args)
     optimizer_step(model, optimizer, args)
     if args.use_discriminator:
         unfreeze_model_parameters(model.discriminator)
@@ -506,15 +507,14 @@ def train(args, batch_getter=None, on_epoch_end=None, valid_dataloader=None):
             model.train()
             if args.use_discriminator:
                 freeze_model_parameters(model.discriminator)
-            for si in range(args.ae_steps):
-                step = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps + si
-                train_ae_step(losses, model, batch_getter.get_unsupervised_batch(), step, accum_steps, args)
-            for si in range(cm_steps):
-                step = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps + si
-                train_cm_step(losses, model, batch_getter.get_unsupervised_batch(), step, accum_steps, args)
-            for si in range(args.sp_steps):
-                step = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps + si
-                train_sp_step(losses, model, batch_getter.get_supervised_batch(), step, accum_steps, args)
+            base = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps
+            subs = [(train_ae_step, batch_getter.get_unsupervised_batch, si) for si in range(args.ae_steps)]
+            subs += [(train_cm_step, batch_getter.get_unsupervised_batch, si) for si in range(cm_steps)]
+            subs += [(train_sp_step, batch_getter.get_supervised_batch, si) for si in range(args.sp_steps)]
+            for i, (fn, get, si) in enumerate(subs):
+                if i == len(subs) - 1:
+                    ddp.arm()                      # last generator sub-step: gradient buckets travel during its backward
+                fn(losses, model, get(), base + si, accum_steps, args)
             optimizer_step(model, optimizer, args)
             if args.use_discriminator:
                 unfreeze_model_parameters(model.discriminator)
@@ -672,7 +672,7 @@ class FusedAdamW(torch.optim.Optimizer):
         ranges = st.active_ranges()
         if not ranges:
             return
-        allreduce_grads(st, ranges)
+        ddp.finish(st, ranges)                 # waits for the buckets that travelled during the backward, reduces the rest
         g = self.param_groups[0]
         key = tuple(ranges)                    # one norm scalar per phase: the D phase may run on its own stream
         ss = self._ss_by_phase.get(key)
@@ -683,12 +683,11 @@ class FusedAdamW(torch.optim.Optimizer):
         for a, b in ranges:
             ops.sumsq(st.grad[a:b], self._ss)
         self.last_grad_norm_sq = self._ss
-        if not self.decoupled:
-            raise NotImplementedError("optim_type 'adam' (L2-coupled decay) is not built; every reference transformer config uses adamw")
         for a, b in ranges:
             self._steps[(a, b)] += 1
             ops.adamw(st.flat[a:b], st.grad[a:b], self._m[a:b], self._v[a:b], self._ss, float(max_norm), float(g["lr"]),
-                      g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps[(a, b)], split_out=st.flat_split[a:b])
+                      g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps[(a, b)], split_out=st.flat_split[a:b],
+                      decoupled=self.decoupled)
 
     def zero_grad(self, set_to_none=True):
         self.model._store().zero_grad()
@@ -752,22 +751,15 @@ class FusedAdamW(torch.optim.Optimizer):
 
 
 def allreduce_grads(st, ranges, scale_fn=None):
-    """Data-parallel gradient exchange (new vs. the single-device reference): ONE RCCL all-reduce
-    per active contiguous gradient range (generator phase: ~17.05 M floats, D phase: 0.28 M), summed then scaled by
-    1/world with a HIP kernel; no-op when torch.distributed is not initialised.  `scale_fn` exists so the exchange
-    logic can be exercised by the world_size-2 gloo test on CPU tensors."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return 0
-    ws = dist.get_world_size()
-    scale_fn = scale_fn or ops.scale_inplace
-    n = 0
-    for a, b in ranges:
-        buf = st.grad[a:b]
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        scale_fn(buf, 1.0 / ws)
-        n += 1
-    return n
+    """Data-parallel gradient exchange of the active gradient ranges on the caller's stream (new vs. the single-device
+    reference): what unast_amd.ddp.finish does for everything that did not already travel during the
+    backward pass.  Sum over ranks, then scaled by 1/world with a HIP kernel; no-op when torch.distributed is not
+    initialised.  `scale_fn` exists so the exchange logic can be exercised by the world_size-2 gloo test on CPU tensors."""
+    ddp._State.scale_fn = scale_fn
+    try:
+        return ddp.finish(st, ranges)
+    finally:
+        ddp._State.scale_fn = None
 
 
 def initialize_model(args):

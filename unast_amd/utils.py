@@ -82,24 +82,22 @@ def init_device(args):
     return torch.device("cuda")
 
 
-class TeacherRatio():
-    """src/utils.py:116-136."""
+class TeacherRatio:
+    """Teacher-forcing ratio schedule with the reference's attribute names (src/utils.py:116-136): constant `val` until
+    `start_step`, then val * gamma^(min(iter, stop_step) - start_step).  (The reference constructs it and never advances it:
+    its `.step()` call is commented out at src/train.py:664, so the ratio stays at teacher_init_val on the hot path.)"""
 
     def __init__(self, args):
+        self.val, self.gamma = args.teacher_init_val, args.teacher_gamma
+        self.start_step, self.stop_step = args.teacher_decay_start, args.teacher_decay_end
         self.iter = 0
-        self.val = args.teacher_init_val
-        self.gamma = args.teacher_gamma
-        self.start_step = args.teacher_decay_start
-        self.stop_step = args.teacher_decay_end
 
     def step(self):
         self.iter += 1
 
     def get_val(self):
-        if self.start_step <= self.iter:
-            power = min(self.iter, self.stop_step) - self.start_step
-            return self.val * (self.gamma ** power)
-        return self.val
+        decayed_for = min(self.iter, self.stop_step) - self.start_step
+        return self.val if self.iter < self.start_step else self.val * self.gamma ** decayed_for
 
 
 def get_teacher_ratio(args):
