@@ -36,6 +36,8 @@ SUSTAINED_MFMA_TFLOPS = 1800.0          # v_mfma_f32_16x16x32_bf16 on random dat
 
 # Algorithmic TFLOP of one train step per GPU (full gen+disc step for c3/c5, generator-only for c2).
 STEP_TFLOP = {"c3": 4.875, "c2": 0.510, "c5": 15.940}
+ATTN_BWD_PRODUCTS = 7          # MFMA products the backward executes per (query, key) tile (5 algorithmic: S and dP are recomputed by the dK/dV kernel)
+ATTN_BWD_KERNEL = "attn_q_kernel<%(n)d,1> + attn_dkv_kernel<%(n)d>"
 
 WORKLOADS = {
     # name: (B, Tt, Tm, L, use_discriminator)
@@ -125,9 +127,9 @@ def make_batch(B, Tt, Tm, seed):
     return tuple(torch.from_numpy(x) for x in synth_batch(B, Tt, Tm, seed=seed, ragged=False))
 
 
-def cpu_baseline_worker(Tt, Tm, L, use_disc, Bs):
-    """Oracle (CPU restatement, pinned against the reference's golden vectors) timed on the host cores: one full
-    gen+disc step (same step definition as the GPU run) on a bounded sample of the workload (Bs utterances)."""
+def cpu_baseline_worker(Tt, Tm, L, use_disc, Bs, budget_s):
+    """Oracle (CPU restatement, pinned against the reference's golden vectors) timed on the host cores: full gen+disc steps
+    (same step definition, same batch size as the GPU run): 1 warm-up + up to 3 timed steps, as many as fit the time budget."""
     from oracle import unast_ref as R
     from unast_amd.portable import portable_tensor
     from unast_amd.spec import state_dict_spec
@@ -142,25 +144,33 @@ def cpu_baseline_worker(Tt, Tm, L, use_disc, Bs):
     m.packed_lstm = True                       # torch's packed-sequence LSTM, as the reference (src/module.py:306,315-316)
     opt = R.AdamW(m.P, lr=1e-3, weight_decay=1e-6)
     batch = make_batch(Bs, Tt, Tm, 0)
+    t_start = time.time()
     t0 = time.time()
     R.full_step(m, opt, batch, use_discriminator=use_disc)
-    dt = time.time() - t0
-    return {"value": round(Bs * Tm / dt, 2), "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": "1 full gen+disc step of the same workload on B=%d utterance(s) (T_text=%d, T_mel=%d, L=%d), fp32 torch-CPU oracle "
-                      "(dropout off), %.1f s" % (Bs, Tt, Tm, L, dt)}
+    warm = time.time() - t0
+    times = []
+    while len(times) < 3 and (time.time() - t_start) + (times[-1] if times else warm) < budget_s:
+        t0 = time.time()
+        R.full_step(m, opt, batch, use_discriminator=use_disc)
+        times.append(time.time() - t0)
+    med = sorted(times)[len(times) // 2] if times else warm
+    return {"value": round(Bs * Tm / med, 2), "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": "full gen+disc steps of the same workload and batch (B=%d, T_text=%d, T_mel=%d, L=%d), fp32 torch-CPU oracle (dropout off): "
+                      "1 warm-up (%.1f s) + %d timed step(s), median %.1f s%s" % (Bs, Tt, Tm, L, warm, len(times), med,
+                                                                              "" if times else " (only the warm-up fitted the time box: cold figure)")}
 
 
-def cpu_baseline(Tt, Tm, L, use_disc, budget_s):
+def cpu_baseline(B, Tt, Tm, L, use_disc, budget_s):
     """Runs the worker in a child process with a hard time box so the default bench always finishes within minutes."""
     import subprocess
     code = ("import sys, json; sys.path.insert(0, %r); import bench; "
-            "print('CPUBASE ' + json.dumps(bench.cpu_baseline_worker(%d, %d, %d, %r, 16)))" % (ROOT, Tt, Tm, L, use_disc))
+            "print('CPUBASE ' + json.dumps(bench.cpu_baseline_worker(%d, %d, %d, %r, %d, %d)))" % (ROOT, Tt, Tm, L, use_disc, B, budget_s))
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
-        out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget_s, env=env)
+        out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget_s + 60, env=env)
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "mel-frames/s", "cores": os.cpu_count(), "kind": "port",
-                "sample": "B=16 step of the same workload did not finish within the %d s time box" % budget_s}
+                "sample": "B=%d steps of the same workload did not finish within the %d s time box" % (B, budget_s + 60)}
     for line in out.stdout.decode().splitlines():
         if line.startswith("CPUBASE "):
             return json.loads(line[len("CPUBASE "):])
@@ -175,11 +185,15 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default=os.environ.get("UNAST_PREC", "bf16x3"), choices=["bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=int, default=110, help="seconds of CPU-oracle stepping (1 warm-up + up to 3 timed steps of the same batch)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the captured step (unast_amd.graphed)")
+    ap.add_argument("--iso-detail", action="store_true", help="print the per-shape table of the isolated steps to stderr")
+    ap.add_argument("--iso-steps", type=int, default=2, help="single-stream eager steps after the timed region whose GEMM / attention launches are timed with HIP events")
     ap.add_argument("--cm-steps", type=int, default=0, help="add this many cross-model (back-translation) sub-steps per step; reported "
                     "separately from the headline metric, which is defined with cm_steps = 0 (SURVEY.md section 8d)")
     ap.add_argument("--cm-max-len", type=int, default=0, help="cap of the autoregressive generation inside the cm sub-step (0 = reference "
                     "defaults 815 mel frames / 300 tokens)")
-    ap.add_argument("--time-every", type=int, default=10, help="HIP-event pairs around the GEMM / attention launches on every N-th step of the timed region")
+    ap.add_argument("--time-every", type=int, default=0, help="eager form only: HIP-event pairs around the GEMM / attention launches on every N-th step of the timed region (0 = none)")
     ap.add_argument("--profile-ops", action="store_true", help="time every op family (adds event overhead; not for the headline number)")
     ap.add_argument("--backend", default=os.environ.get("UNAST_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) is the product path; gloo only rehearses the multi-rank logic on a 1-GPU box")
@@ -226,8 +240,18 @@ def main():
         model.speech_m.infer_max_len = model.text_m.infer_max_len = a.cm_max_len
     losses = defaultdict(list)
 
+    use_graph = (not a.no_graph) and os.environ.get("UNAST_GRAPH", "1") != "0" and a.cm_steps == 0 and not dist_on \
+        and not a.profile_ops and a.time_every == 0
+    stepper = None
+    if use_graph:
+        from unast_amd.graphed import GraphedTrainStep
+        stepper = GraphedTrainStep(model, opt, sched, args)
+
     def one_step(i):
-        train.train_step(losses, model, opt, sched, batches, i, args, defer_d_phase=True)      # as train() does; the timed region ends with a device synchronise
+        if stepper is not None:          # replay of the captured step (the first three calls run eagerly / capture it)
+            stepper(losses, batches, i)
+        else:
+            train.train_step(losses, model, opt, sched, batches, i, args, defer_d_phase=True)      # as train() does; the timed region ends with a device synchronise
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -236,26 +260,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for i in range(a.warmup):
+    n_prime = 3 if stepper is not None else 0     # eager generator phase, eager shifted step, capture + first replay: before the W warm-up steps
+    for i in range(n_prime + a.warmup):
         one_step(i)
+    sync()
+    # In-region HIP-event pairs exist only in the eager form (a replayed graph has no per-kernel host hooks) and only with --time-every:
+    # they cost ~15 us of host time per launch, enough to make the host the bottleneck.  The roofline figures come from the isolated
+    # single-stream steps after the timed region.
     timed = ["gemm", "attn_fwd", "attn_bwd"]
     if a.profile_ops:
         timed += ["layernorm_fwd", "layernorm_bwd", "colsum", "bn_fwd", "bn_bwd", "embed_fwd", "embed_bwd", "posenc_fwd", "posenc_bwd", "rowmask",
                   "add_inplace", "add_strided", "specaugment", "disc_gather", "disc_scatter", "speech_loss_fwd", "speech_loss_bwd", "text_loss_fwd",
                   "text_loss_bwd", "bce_logits", "disc_targets", "lstm_fwd", "lstm_bwd", "leaky_dropout", "sumsq", "adamw", "scale_inplace"]
-    sync()
-    # HIP-event pairs around every GEMM / attention launch of a step cost ~15 ms of host time per step -- enough to make the host
-    # the bottleneck (40 ms of enqueueing against 36 ms of GPU work) -- so they are on for every `every`-th step of the timed region.
-    every = 1 if (a.steps <= 4 or a.profile_ops) else a.time_every
-    n_timed = len(range(0, a.steps, every))
+    in_region = (stepper is None) and (a.profile_ops or a.time_every > 0)
+    every = 1 if a.profile_ops else max(a.time_every, 1)
     with OpTimer(ops, timed) as ot:
+        ot.active = False
         t0 = time.perf_counter()
         for i in range(a.steps):
-            ot.active = (i % every == 0)
-            one_step(a.warmup + i)
+            ot.active = in_region and (i % every == 0)
+            one_step(n_prime + a.warmup + i)
         t_host = time.perf_counter() - t0          # host-side enqueue time (kernels run asynchronously)
         sync()
         dt = time.perf_counter() - t0
+    n_timed = len(range(0, a.steps, every)) if in_region else 0
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -264,86 +292,94 @@ def main():
     ms = dt / a.steps * 1e3
     frames = B * Tm * world
     value = frames / (dt / a.steps)
-
+    if stepper is not None:
+        stepper.flush(losses)                      # the last step's discriminator phase (every timed call ran one D phase and one generator phase)
+    sync()
     last = {k: float(v[-1]) for k, v in losses.items()}
     finite = all(v == v and abs(v) < 1e30 for v in last.values())
-    # Isolated launch durations of the same kernels: two extra steps AFTER the timed region with everything on one stream (every
-    # rank runs them: the step contains the collectives).  With the side streams on, a launch in the timed region shares the chip
-    # with launches of other streams, so its duration says less about the kernel itself; the rocprofv3 summaries in profiles/ are
-    # isolated durations too (under the profiler the host is the bottleneck and the streams hardly overlap).
-    iso = None
-    if config.SIDE_STREAMS:
-        config.SIDE_STREAMS = False
-        try:
-            with OpTimer(ops, ["gemm"]) as ot_iso:
-                for i in range(2):
-                    one_step(a.warmup + a.steps + i)
-                sync()
-            iso = ot_iso.summary()["gemm"]
-        finally:
-            config.SIDE_STREAMS = True
+    # Isolated launch durations: extra steps AFTER the timed region, launched kernel by kernel with everything on ONE stream and a
+    # HIP-event pair around every GEMM / attention launch on that stream (every rank runs them: the step contains the collectives).
+    # These are what `roofline` reports and what the rocprofv3 summaries in profiles/ show (average duration per kernel).
+    side = config.SIDE_STREAMS
+    config.SIDE_STREAMS = False
+    try:
+        with OpTimer(ops, ["gemm", "attn_fwd", "attn_bwd"]) as ot_iso:
+            for i in range(a.iso_steps):
+                train.train_step(losses, model, opt, sched, batches, n_prime + a.warmup + a.steps + i, args)
+            sync()
+        iso = ot_iso.summary()
+    finally:
+        config.SIDE_STREAMS = side
+    if dist_on:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     if rank != 0:
         return
     summ = ot.summary()
-    # ---- dominant kernel family + roofline ------------------------------------------------------------------
-    fam = {}
-    for n in ("gemm", "attn_fwd", "attn_bwd"):
-        calls = sum(v[0] for v in summ[n].values())
-        tot = sum(v[1] for v in summ[n].values())
-        fl = sum((gemm_flops(k) if n == "gemm" else attn_flops(n, k)) * v[0] for k, v in summ[n].items())
-        fam[n] = dict(calls=calls, ms=tot, flops=fl, bytes=(sum(gemm_bytes(k) * v[0] for k, v in summ[n].items()) if n == "gemm" else 0.0))
-    dom = max(fam, key=lambda n: fam[n]["ms"])
-    d = fam[dom]
-    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-    kernel_name = {"gemm": "gemm_kernel<*,*,%d> (all linear/conv contractions)" % config.NSPLIT,
-                   "attn_fwd": "attn_q_kernel<%d,0>" % config.NSPLIT, "attn_bwd": "attn_q_kernel<%d,1> + attn_dkv_kernel<%d>" % (config.NSPLIT, config.NSPLIT)}[dom]
-    if dom == "gemm":
-        # The d=256 contractions are priced against HBM: with fp32 activations and 3 MFMAs per product they sit below the ridge
-        # point, the MFMA pipe is 40 % busy (rocprofv3 PMC) and a load-only build of the kernel already takes 70 % of its time
-        # (csrc/gemm.hip).  The MFMA view is kept beside it.
-        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
-        traffic = None
-        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+
+    def family(su, n):
+        calls = sum(v[0] for v in su[n].values())
+        tot = sum(v[1] for v in su[n].values())
+        fl = sum((gemm_flops(k) if n == "gemm" else attn_flops(n, k)) * v[0] for k, v in su[n].items())
+        by = sum(gemm_bytes(k) * v[0] for k, v in su[n].items()) if n == "gemm" else 0.0
+        return dict(calls=calls, ms=tot, flops=fl, bytes=by)
+    fam = {n: family(iso, n) for n in ("gemm", "attn_fwd", "attn_bwd")}
+    steps_iso = max(a.iso_steps, 1)
+
+    def mfma_entry(n, kernel):
+        d = fam[n]
+        tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": d["calls"] / steps_iso,
+                "avg_launch_us": round(d["ms"] * 1e3 / max(d["calls"], 1), 2), "ms_per_step": round(d["ms"] / steps_iso, 3),
+                "mfma_issue_frac_of_peak": round(tf * (config.NSPLIT if n == "attn_fwd" else config.NSPLIT * ATTN_BWD_PRODUCTS / 5.0) / PEAK_MFMA_BF16_TFLOPS, 4)}
+    g = fam["gemm"]
+    gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0
+    gtf = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+    traffic = None
+    for tp in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        tp = os.path.join(ROOT, "profiles", tp)
         if a.workload == "c3" and config.NSPLIT == 3 and os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                g = [v for k, v in tj["kernels"].items() if "gemm_kernel" in k]
-                traffic = round(sum(v["hbm_MB_per_launch"] * v["launches"] for v in g) / sum(v["launches"] for v in g) * 1e6, 0)
+                gk = [v for k, v in tj["kernels"].items() if "gemm_kernel" in k or "gemm_group" in k]
+                traffic = round(sum(v["hbm_MB_per_launch"] * v["launches"] for v in gk) / sum(v["launches"] for v in gk) * 1e6, 0)
+                break
             except Exception:
                 traffic = None
-        roofline = {"kernel": kernel_name, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["calls"], 1), 0),
-                    "launches_per_step": d["calls"] / n_timed, "timed_steps": n_timed, "avg_launch_us": round(d["ms"] * 1e3 / max(d["calls"], 1), 2),
-                    "concurrent_streams": (4 if config.WGRAD_STREAMS else 3) if config.SIDE_STREAMS else 1,
-                    "isolated": (None if not iso else (lambda c, ms, by: {"avg_launch_us": round(ms * 1e3 / max(c, 1), 2), "achieved": round(by / (ms * 1e-3) / 1e9, 1),
-                                                                          "frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})(
-                        sum(v[0] for v in iso.values()), sum(v[1] for v in iso.values()), sum(gemm_bytes(k) * v[0] for k, v in iso.items()))),
-                    "mfma_view": {"achieved_tflops": round(ach, 2), "frac_of_2500_dense_bf16": round(ach / PEAK_MFMA_BF16_TFLOPS, 4),
-                                  "mfma_issue_tflops": round(ach * config.NSPLIT, 1), "sustained_mfma_peak_measured_tflops": SUSTAINED_MFMA_TFLOPS},
-                    "note": "achieved = algorithmic bytes (fp32 A + B + C and epilogue operands, each once; conv inputs once, not per tap) / HIP-event "
-                            "time of these launches inside the timed region (event pairs on every --time-every-th step when steps > 4, see timed_steps; text side, speech side and discriminator run on three HIP streams and the "
-                            "speech side's weight gradients on a fourth, so a launch's duration includes time it shares the chip with kernels of the "
-                            "others; `isolated` = the same launches in two extra single-stream steps after the timed region, comparable with profiles/); traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE per launch from "
-                            "profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 passes of this command), null if that file is absent; mfma_view: 2MNK "
-                            "FLOPs per contraction, each product costs %d bf16 MFMAs in %s mode; sustained peak = tools/mfma_peak.cpp on this chip" % (config.NSPLIT, a.precision),
-                    "families_ms_per_step": {n: round(fam[n]["ms"] / n_timed, 3) for n in fam}}
-    else:
-        roofline = {"kernel": kernel_name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": d["calls"] / n_timed, "timed_steps": n_timed, "avg_launch_us": round(d["ms"] * 1e3 / max(d["calls"], 1), 2),
-                    "mfma_issue_frac": round(ach * config.NSPLIT / PEAK_MFMA_BF16_TFLOPS, 4),
-                    "note": "achieved = algorithmic FLOPs (4*B*H*Tq*Tk*64 per attention forward, x2.5 backward) / HIP-event time of these launches "
-                            "inside the timed region; each product costs %d bf16 MFMAs in %s mode" % (config.NSPLIT, a.precision),
-                    "families_ms_per_step": {n: round(fam[n]["ms"] / n_timed, 3) for n in fam}}
+    roofline = {"kernel": "gemm_kernel<*,*,%d> (all linear / conv contractions: forward, dgrad, grouped wgrad)" % config.NSPLIT,
+                "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                "traffic": traffic, "algorithmic_bytes_per_launch": round(g["bytes"] / max(g["calls"], 1), 0),
+                "launches_per_step": g["calls"] / steps_iso, "avg_launch_us": round(g["ms"] * 1e3 / max(g["calls"], 1), 2),
+                "ms_per_step": round(g["ms"] / steps_iso, 3), "measured_over": "%d single-stream eager step(s) after the timed region" % a.iso_steps,
+                "mfma_view": {"achieved_tflops": round(gtf, 2), "frac_of_2500_dense_bf16": round(gtf / PEAK_MFMA_BF16_TFLOPS, 4),
+                              "mfma_issue_tflops": round(gtf * config.NSPLIT, 1), "sustained_mfma_peak_measured_tflops": SUSTAINED_MFMA_TFLOPS},
+                "attn_fwd": mfma_entry("attn_fwd", "attn_q_kernel<%d,0>" % config.NSPLIT),
+                "attn_bwd": mfma_entry("attn_bwd", ATTN_BWD_KERNEL % {"n": config.NSPLIT}),
+                "note": "dominant family = GEMM.  achieved = algorithmic bytes (fp32 A + B + C and epilogue operands, each once; conv inputs once, not "
+                        "per tap) / HIP-event time of these launches, taken on the launch stream in the isolated single-stream steps after the "
+                        "timed region (the timed region replays a captured HIP graph with four streams: no per-kernel host hooks there, and a "
+                        "launch would share the chip with the other streams' kernels); traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE per launch "
+                        "from profiles/ (separate rocprofv3 passes of this command), null if absent; mfma_view / attn_*: 2MNK FLOPs per "
+                        "contraction, 4*B*H*Tq*Tk*64 per attention forward (x2.5 backward, causal at T(T+1)/2); each product costs %d bf16 MFMAs in "
+                        "%s mode; sustained MFMA peak = tools/mfma_peak.cpp on this chip" % (config.NSPLIT, a.precision)}
+    if in_region and n_timed:
+        fr = {n: family(summ, n) for n in ("gemm", "attn_fwd", "attn_bwd")}
+        roofline["overlapped_streams"] = {"families_ms_per_step": {n: round(fr[n]["ms"] / n_timed, 3) for n in fr}, "timed_steps": n_timed,
+                                          "gemm_avg_launch_us": round(fr["gemm"]["ms"] * 1e3 / max(fr["gemm"]["calls"], 1), 2),
+                                          "note": "event pairs inside the timed region (eager form only): durations include time shared with other streams"}
     out = {"metric": "mel-frames/sec/node (train step, gen+disc) at B=32,T_mel=800; 1/2/4/8-GPU scaling",
            "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16x3" if config.NSPLIT == 3 else "bf16", "data": "synthetic",
            "dist_backend": (a.backend if dist_on else None),
-           "config": {"workload": "%s: full adversarial gen+disc train step (AE+SP+clip/AdamW, D step+clip/AdamW), per-GPU B=%d, T_text=%d, T_mel=%d, "
-                                  "num_layers=%d, d=256, 4 heads, FFN 1024, 2x bi-LSTM(64) discriminator, dropout/noise/SpecAugment active%s" % (
-                                      a.workload, B, Tt, Tm, L, (" + %d cross-model sub-step(s) with K/V-cached generation (NOT the headline configuration)" % a.cm_steps) if a.cm_steps else ""),
+           "launch_mode": ("hip-graph replay of the captured step (unast_amd.graphed), %d untimed priming calls" % n_prime) if stepper is not None
+                          else "eager (one Python launch per kernel)" + ("; gradient buckets all-reduced during the backward (unast_amd.ddp)" if dist_on else ""),
+           "config": {"workload": "%s: %s train step (AE+SP+clip/AdamW%s), per-GPU B=%d, T_text=%d, T_mel=%d, "
+                                  "num_layers=%d, d=256, 4 heads, FFN 1024%s, dropout/noise/SpecAugment active%s" % (
+                                      a.workload, "full adversarial gen+disc" if use_disc else "generator-only", ", D step+clip/AdamW" if use_disc else "", B, Tt, Tm, L,
+                                      ", 2x bi-LSTM(64) discriminator" if use_disc else "",
+                                      (" + %d cross-model sub-step(s) with K/V-cached generation (NOT the headline configuration)" % a.cm_steps) if a.cm_steps else ""),
                       "global_batch": B * world, "parallelism": "dp%d" % world,
                       "precision": "split-bf16 (hi/lo) MFMA operands, fp32 accumulate and fp32 activations" if config.NSPLIT == 3 else "bf16 MFMA operands, fp32 accumulate"},
            "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
@@ -356,10 +392,10 @@ def main():
                              "note": "SURVEY.md section 8(d) table: multiply-add = 2, backward = 2x forward, causal self-attention at T(T+1)/2"}
     if world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(Tt, Tm, L, use_disc, 150)
+            out["cpu_baseline"] = cpu_baseline(B, Tt, Tm, L, use_disc, a.cpu_budget)
         except Exception as e:  # the checker must never take the bench down
             out["cpu_baseline"] = {"error": repr(e)}
-    if a.profile_ops:
+    if a.profile_ops and n_timed:
         prof = {n: round(sum(v[1] for v in summ[n].values()) / n_timed, 3) for n in summ}
         sys.stderr.write("per-op ms/step: " + json.dumps(dict(sorted(prof.items(), key=lambda kv: -kv[1]))) + "\n")
         for n in ("gemm", "attn_fwd", "attn_bwd"):
@@ -367,6 +403,13 @@ def main():
             for k, v in rows:
                 fl = (gemm_flops(k) if n == "gemm" else attn_flops(n, k))
                 sys.stderr.write("  %-9s %-28s calls/step %5.1f  avg %8.1f us  %7.1f TF/s\n" % (n, k, v[0] / n_timed, v[1] * 1e3 / v[0], fl * v[0] / (v[1] * 1e-3) / 1e12))
+    if a.iso_detail:
+        for n in ("gemm", "attn_fwd", "attn_bwd"):
+            rows = sorted(iso[n].items(), key=lambda kv: -kv[1][1])[:16]
+            for k, v in rows:
+                fl = (gemm_flops(k) if n == "gemm" else attn_flops(n, k))
+                sys.stderr.write("  iso %-9s %-44s calls/step %5.1f  avg %8.1f us  total %7.3f ms/step  %7.1f TF/s\n" % (
+                    n, k, v[0] / steps_iso, v[1] * 1e3 / v[0], v[1] / steps_iso, fl * v[0] / (v[1] * 1e-3) / 1e12))
     print(json.dumps(out))
 
 

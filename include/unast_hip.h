@@ -187,6 +187,9 @@ int unast_text_loss_bwd(const float* logits, int ldl, const int64_t* gold, int r
 /* discriminator_target (src/train.py:150-164, 319-320): smoothed labels 0.9 (text rows: perm[i] < B) / 0.1 (speech),
  * flipped (1-y) when flip=1 (generator phase). */
 int unast_disc_targets(const int64_t* perm, int n, int B, int flip, float smoothing, float* out, hipStream_t stream);
+/* the row permutation of discriminator_shuffle_batch (torch.randperm, src/train.py:323) from the counter RNG of the dropout
+ * kernels: uniform over permutations, a function of (seed, stream_id, RNG epoch), n <= 4096; capturable in a HIP graph. */
+int unast_randperm(int64_t* out, int n, unsigned int seed, unsigned int stream_id, hipStream_t stream);
 /* discriminator_loss (src/train.py:147-148): mean BCE-with-logits; logits/dlogits may be strided (ldx/ldd elements).
  * loss/dlogits may be NULL; dlogits is scaled by the device scalar *gscale. */
 int unast_bce_logits(const float* logits, int ldx, const float* targets, int n, const float* gscale, float* loss, float* dlogits,
@@ -222,6 +225,10 @@ int unast_adamw(float* p, const float* g, float* m, float* v, int64_t n, const d
                 float beta1, float beta2, float eps, float weight_decay, int step, float* split_out, int decoupled,
                 const float* dev_hyper, hipStream_t stream);
 int unast_split_f32(const float* src, float* dst, int64_t n, hipStream_t stream);
+/* Writes n <= 16 32-bit words (read from HOST memory at call time, passed by value in the kernel arguments) to device memory:
+ * refreshes the block a captured step reads (RNG epoch of unast_set_rng_epoch, dev_hyper triples of unast_adamw) once per
+ * replay; stands where the reference's Python passes lr / step to torch.optim (src/train.py:361, 654-655). */
+int unast_set_words(unsigned int* dst, const unsigned int* host_words, int n, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -250,32 +250,38 @@ def test_full_batch_step_is_reproducible_and_finite():
 
 def test_deferred_discriminator_phase_matches_joined():
     """train_step(defer_d_phase=True) (the D phase stays on its own stream and overlaps the next step's generator forward, as
-    train() and bench.py run it) reaches the same parameters and losses as the default, fully joined, form over several
-    consecutive steps."""
+    train() and bench.py run it) reaches the same losses as the default, fully joined, form over several consecutive steps.
+    The learning rate is small enough (2e-4) that Adam does not amplify accumulation-order noise within four steps, yet one
+    missed or stale update would move the next step's losses by ~1e-2 relative (checked below by skipping one on purpose)."""
     from collections import defaultdict
     from unast_amd import train
     from unast_amd.engine import join_streams
     from unast_amd.portable import synth_batch
     res = []
-    for defer in (False, True):
-        args, model, opt, sd = build(2, 2e-3)
+    for mode in ("joined", "deferred", "stale"):
+        args, model, opt, sd = build(2, 2e-4)
         batch = tuple(torch.from_numpy(x) for x in synth_batch(8, 60, 256, seed=2, ragged=True))
         batches = dict(unsup=[batch], sup=[batch], disc=[batch], cm=[])
         losses = defaultdict(list)
         for i in range(4):
-            train.train_step(losses, model, opt, None, batches, i + 1, args, defer_d_phase=defer)
+            if mode == "stale" and i == 2:      # what an ordering bug would look like: the next step reads D without this step's update
+                from unast_amd import ops
+                st = model._store()
+                saved = st.flat.clone()
+                train.train_step(losses, model, opt, None, batches, i + 1, args, defer_d_phase=False)
+                a, b = st.regions["disc"]
+                st.flat[a:b].copy_(saved[a:b])
+                ops.split_f32(st.flat, st.flat_split)
+                continue
+            train.train_step(losses, model, opt, None, batches, i + 1, args, defer_d_phase=(mode == "deferred"))
         join_streams()
         torch.cuda.synchronize()
-        res.append(({k: [float(x) for x in v] for k, v in losses.items()}, {n: p.detach().cpu().clone() for n, p in model.named_parameters()}))
-    # Steps 1-2 pin the dependency (step 2's losses are computed with step 1's discriminator update: a stale read would be a
-    # percent-level change); from step 3 on Adam at this learning rate amplifies accumulation-order noise chaotically (two
-    # JOINED runs already differ by ~7e-4 in loss and ~7e-2 in the smallest tensors, tools/defer_noise.py).
-    for k in res[0][0]:
-        for i, (a, b) in enumerate(zip(res[0][0][k], res[1][0][k])):
-            tol = 1e-4 if i < 2 else 2e-2
-            assert abs(a - b) <= tol * max(1.0, abs(a)), (k, i, a, b)
-    worst = 0.0
-    for n in res[0][1]:
-        a, b = res[0][1][n].double(), res[1][1][n].double()
-        worst = max(worst, float((a - b).norm() / a.norm().clamp_min(1e-12)))
-    assert worst < 0.3, worst
+        res.append({k: [float(x) for x in v] for k, v in losses.items()})
+    gap = 0.0
+    for k in res[0]:
+        for i, (a, b) in enumerate(zip(res[0][k], res[1][k])):
+            gap = max(gap, abs(a - b) / max(1.0, abs(a)))
+            assert abs(a - b) <= 1e-3 * max(1.0, abs(a)), (k, i, a, b)
+    # that tolerance is meaningful: the deliberately stale run differs by clearly more in the D-dependent losses of the step after
+    stale_gap = max(abs(a - b) / max(1.0, abs(a)) for k in ("d", "d_ae", "sp_d") for a, b in zip(res[0][k][3:], res[2][k][3:]))
+    assert stale_gap > 3 * max(gap, 1e-4), (stale_gap, gap)

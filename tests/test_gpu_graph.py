@@ -1,0 +1,120 @@
+"""The train step replayed from a captured HIP graph (unast_amd.graphed) against the same steps launched kernel by kernel."""
+from collections import defaultdict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+D = torch.device("cuda:0")
+
+
+def build(L, lr, use_discriminator=True, sched_type=None):
+    from unast_amd import train, utils
+    from unast_amd.configs import make_args
+    from unast_amd.portable import portable_tensor
+    from unast_amd.spec import state_dict_spec
+    args = make_args(num_layers=L, ae_steps=1, sp_steps=1, d_steps=1, cm_steps=0, use_discriminator=use_discriminator, lr=lr,
+                     sched_type=sched_type, warmup_steps=3)
+    train.DEVICE = D
+    utils.set_seed(0)
+    _, _, model, opt, sched = train.initialize_model(args)
+    sd = {k: torch.from_numpy(portable_tensor(k, shp, 1234)) for k, shp in state_dict_spec(L, use_discriminator=use_discriminator).items()}
+    model.load_state_dict(sd)
+    return args, model, opt, sched
+
+
+def batches_for(i, B=4, Tt=28, Tm=96):
+    from unast_amd.portable import synth_batch
+    mk = lambda s: tuple(torch.from_numpy(x).to(D) for x in synth_batch(B, Tt, Tm, seed=s, ragged=True))
+    return dict(unsup=[mk(3 * i)], sup=[mk(3 * i + 1)], disc=[mk(3 * i + 2)], cm=[])
+
+
+@pytest.mark.parametrize("use_disc", [True, False])
+def test_graph_replay_and_eager_steps_agree(use_disc):
+    """Six outer steps with a different batch per sub-step and a learning-rate schedule (linear warm-up then decay, so every
+    step has another lr): losses of every sub-step, the final parameters and the optimizer's step counts agree between
+    train_step(defer_d_phase=True) and GraphedTrainStep (two eager calls, one capture, three pure replays).  RNG sites off, so
+    the two runs differ by accumulation-order noise only."""
+    from unast_amd import train, utils
+    from unast_amd.engine import join_streams
+    from unast_amd.graphed import GraphedTrainStep
+    utils.set_deterministic(True)
+    res = []
+    for graphed in (False, True):
+        args, model, opt, sched = build(2, 4e-4, use_discriminator=use_disc, sched_type="linear")
+        args.epochs, args.epoch_steps = 1, 12
+        _, _, model, opt, sched = train.initialize_model(args)       # scheduler built with these totals
+        from unast_amd.portable import portable_tensor
+        from unast_amd.spec import state_dict_spec
+        model.load_state_dict({k: torch.from_numpy(portable_tensor(k, shp, 1234)) for k, shp in state_dict_spec(2, use_discriminator=use_disc).items()})
+        sched.step()                                                 # lr > 0 at the first step
+        losses = defaultdict(list)
+        stepper = GraphedTrainStep(model, opt, sched, args) if graphed else None
+        for i in range(6):
+            if graphed:
+                stepper(losses, batches_for(i), i)
+            else:
+                train.train_step(losses, model, opt, sched, batches_for(i), i, args, defer_d_phase=True)
+        if graphed:
+            assert len(stepper.graphs) == 1
+            stepper.flush(losses)
+        join_streams()
+        torch.cuda.synchronize()
+        res.append(({k: [float(x) for x in v] for k, v in losses.items()}, model._store().flat.detach().cpu().clone(),
+                    dict(opt._steps), opt.param_groups[0]["lr"]))
+    (la, pa, sa, lra), (lb, pb, sb, lrb) = res
+    assert sa == sb and lra == lrb and set(la) == set(lb)
+    for k in la:
+        assert len(la[k]) == len(lb[k]) == 6, (k, len(la[k]), len(lb[k]))
+        for i, (x, y) in enumerate(zip(la[k], lb[k])):
+            assert abs(x - y) <= 3e-4 * max(1.0, abs(x)), (k, i, x, y)
+    d = (pa - pb).abs()
+    # Adam moves an element with a (near-)zero gradient by +-lr per step on rounding noise: a small fraction may differ by a few lr
+    assert float(d.max()) <= 6 * 4e-4 and float((d > 2e-5).float().mean()) < 0.02, (float(d.max()), float((d > 2e-5).float().mean()))
+
+
+def test_graph_replays_draw_fresh_masks_and_permutations():
+    """With the RNG sites on, replays of ONE captured graph on the SAME batch give different losses (dropout / noise /
+    SpecAugment masks and the discriminator's row permutation follow the RNG epoch in device memory), all finite, and the
+    parameters keep moving."""
+    from unast_amd import utils
+    from unast_amd.graphed import GraphedTrainStep
+    utils.set_deterministic(False)
+    try:
+        args, model, opt, sched = build(2, 2e-4)
+        stepper = GraphedTrainStep(model, opt, None, args)
+        losses = defaultdict(list)
+        b = batches_for(0)
+        for i in range(6):
+            stepper(losses, b, i)
+        stepper.flush(losses)
+        torch.cuda.synchronize()
+        for k, v in losses.items():
+            vals = [float(x) for x in v]
+            assert len(vals) == 6 and all(np.isfinite(vals)), (k, vals)
+            assert len(set(round(x, 6) for x in vals[3:])) == 3, (k, vals)      # calls 3-5 are pure replays
+        # same (seed, stream) but another epoch -> another permutation
+        from unast_amd import ops
+        ops.set_step_state(1, {}); p1 = ops.randperm(64, 5, 1, D)
+        ops.set_step_state(2, {}); p2 = ops.randperm(64, 5, 1, D)
+        ops.set_step_state(1, {}); p3 = ops.randperm(64, 5, 1, D)
+        assert sorted(p1.tolist()) == list(range(64)) and sorted(p2.tolist()) == list(range(64))
+        assert p1.tolist() != p2.tolist() and p1.tolist() == p3.tolist()
+    finally:
+        utils.set_deterministic(True)
+        from unast_amd import ops
+        ops.rng_epoch_counter().zero_()
+
+
+def test_randperm_is_uniform():
+    """Every position receives every value about equally often (4096 draws of a 16-permutation)."""
+    from unast_amd import ops
+    ops.rng_epoch_counter().zero_()
+    n, draws = 16, 4096
+    counts = torch.zeros(n, n)
+    for s in range(draws):
+        p = ops.randperm(n, s, 1, D).cpu()
+        counts[torch.arange(n), p] += 1
+    exp = draws / n
+    assert float((counts - exp).abs().max()) < 6 * (exp ** 0.5), float((counts - exp).abs().max())

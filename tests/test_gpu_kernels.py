@@ -337,7 +337,7 @@ def test_adam_l2_form_and_device_hyper_parameters():
         ss.zero_(); ops.sumsq(gr.to(D), ss)
         ops.adamw(p, gr.to(D), m, v, ss, 1.0, 2e-3, 0.9, 0.999, 1e-8, 1e-2, step, decoupled=False)
         assert relerr(p, ref.detach()) < 2e-6, step
-        hyper.copy_(torch.tensor([2e-3, 1 - 0.9 ** step, math.sqrt(1 - 0.999 ** step)]))
+        hyper.copy_(torch.tensor(ops.adam_hyper(2e-3, 0.9, 0.999, step), dtype=torch.float64).float())
         ops.adamw(p2, gr.to(D), m2, v2, ss, 1.0, 123.0, 0.9, 0.999, 1e-8, 1e-2, 0, decoupled=False, dev_hyper=hyper)
         assert torch.equal(p2, p) and torch.equal(m2, m) and torch.equal(v2, v), step
 

@@ -219,6 +219,30 @@ extern "C" int unast_text_loss_bwd(const float* logits, int ldl, const int64_t* 
     return unast_check_launch("unast_text_loss_bwd");
 }
 
+// Uniform random permutation of 0..n-1 (torch.randperm at src/train.py:323): i.i.d. 32-bit keys from the counter RNG, ranked
+// with the index as tie-break.  One workgroup; n <= 4096 (2 x batch rows).
+__global__ __launch_bounds__(256) void randperm_kernel(long long* __restrict__ out, int n, uint32_t seed, uint32_t stream) {
+    __shared__ uint32_t keys[4096];
+    const uint32_t rk = rng_row_key(seed, stream, 0x9E3779B9u);
+    for (int i = threadIdx.x; i < n; i += 256) keys[i] = rng_u32(rk, (uint32_t)i);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const uint32_t k = keys[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t kj = keys[j];
+            r += (kj < k || (kj == k && j < i)) ? 1 : 0;
+        }
+        out[r] = i;
+    }
+}
+
+extern "C" int unast_randperm(int64_t* out, int n, unsigned int seed, unsigned int stream_id, hipStream_t stream) {
+    UNAST_REQUIRE(out && n > 0 && n <= 4096, "unast_randperm: need 0 < n <= 4096 (got %d)", n);
+    hipLaunchKernelGGL(randperm_kernel, dim3(1), dim3(256), 0, stream, (long long*)out, n, seed, stream_id);
+    return unast_check_launch("unast_randperm");
+}
+
 extern "C" int unast_disc_targets(const int64_t* perm, int n, int B, int flip, float smoothing, float* out, hipStream_t stream) {
     UNAST_REQUIRE(perm && out && n > 0, "unast_disc_targets: bad arguments");
     hipLaunchKernelGGL(disc_targets_kernel, dim3(1), dim3(256), 0, stream, perm, n, B, flip, smoothing, out);
@@ -232,3 +256,5 @@ extern "C" int unast_bce_logits(const float* logits, int ldx, const float* targe
     hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, stream, logits, ldx, targets, n, gscale, loss, dlogits, ldd);
     return unast_check_launch("unast_bce_logits");
 }
+
+UNAST_DEFINE_RNG_EPOCH_SETTER(loss)

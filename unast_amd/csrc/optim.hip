@@ -96,6 +96,23 @@ extern "C" int unast_adamw(float* p, const float* g, float* m, float* v, int64_t
     return unast_check_launch("unast_adamw");
 }
 
+// Up to 16 32-bit words, passed BY VALUE in the kernel arguments, written to device memory: how the host refreshes the
+// step-state block (RNG epoch, learning rate, bias corrections) that a captured train step reads -- no host buffer has to
+// stay untouched until an asynchronous copy has run.
+struct StepWords { unsigned int w[16]; };
+__global__ __launch_bounds__(64) void set_words_kernel(unsigned int* __restrict__ dst, StepWords v, int n) {
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = v.w[i];
+}
+
+extern "C" int unast_set_words(unsigned int* dst, const unsigned int* host_words, int n, hipStream_t stream) {
+    UNAST_REQUIRE(dst && host_words && n > 0 && n <= 16, "unast_set_words: need 1..16 words");
+    StepWords v;
+    for (int i = 0; i < 16; ++i) v.w[i] = i < n ? host_words[i] : 0u;
+    hipLaunchKernelGGL(set_words_kernel, dim3(1), dim3(64), 0, stream, dst, v, n);
+    return unast_check_launch("unast_set_words");
+}
+
 extern "C" int unast_split_f32(const float* src, float* dst, int64_t n, hipStream_t stream) {
     UNAST_REQUIRE(src && dst && n > 0 && (n & 3) == 0, "unast_split_f32: need n %% 4 == 0 (n=%lld)", (long long)n);
     UNAST_REQUIRE(((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "unast_split_f32: buffers must be 16-byte aligned");

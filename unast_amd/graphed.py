@@ -1,0 +1,219 @@
+"""The train step as HIP-graph replays.
+
+One outer step of the reference's hot loop (/root/reference/src/train.py:602-655) is ~2 500 kernel launches; issued one by one
+from Python the host needs 18-30 ms per step, which bounds small configurations outright (BASELINE config 2) and leaves the
+large one a slow host away from it.  `GraphedTrainStep` captures the step once per input shape -- four HIP streams with their
+fork / join events included -- and replays it; per replay the host does three things: copies the batch into the static input
+buffers, writes 16 words of step state (RNG epoch, learning rate, Adam bias corrections: ops.set_step_state) and launches the
+graph.
+
+What makes the step capturable:
+  * dropout / noise / SpecAugment / permutation masks are functions of (seed, stream, row, col, EPOCH) with the epoch read from
+    device memory (csrc/common.h rng_epoch), so a replay draws fresh masks while forward and backward of one replay agree;
+  * clip + AdamW read lr and the bias corrections from device memory (unast_adamw dev_hyper);
+  * the discriminator's row permutation comes from the same counter RNG (unast_randperm) instead of torch.randperm;
+  * losses are device scalars, gathered into one vector inside the graph and snapshotted after the replay (no host sync).
+
+Schedule: as train_step(defer_d_phase=True) -- the discriminator phase of step k-1 (its encoders' forward, the LSTM forward /
+backward, its clip + AdamW) shares the chip with the generator forward of step k.  In eager mode that overlap spans two calls;
+a graph cannot leave work behind, so the captured unit is the SHIFTED step  [ D phase of step k-1  ||  generator phase of
+step k ]  with the same dependencies (D update before the generator's own D call, all on the discriminator's stream; generator
+update after everything).  The first call runs its generator phase eagerly, `flush()` runs the last pending D phase.
+
+Not capturable, falls back to train.train_step: cm_steps > 0 (data-dependent autoregressive generation) and an initialised
+torch.distributed group (collectives stay eager: unast_amd.ddp).
+"""
+from collections import defaultdict
+
+import torch
+
+from . import config, ddp, ops
+from . import train as T
+from .engine import join_streams
+from .utils import is_deterministic
+
+MAX_GRAPHS = 4
+
+
+class _Captured:
+    __slots__ = ("graph", "loss_keys", "loss_vec", "ranges")
+
+
+class GraphedTrainStep:
+    """Drop-in for train.train_step(losses, model, optimizer, scheduler, batches, step, args, defer_d_phase=True)."""
+
+    def __init__(self, model, optimizer, scheduler, args):
+        if not isinstance(optimizer, T.FusedAdamW):
+            raise TypeError("GraphedTrainStep needs the FusedAdamW built by train.initialize_model")
+        self.model, self.opt, self.sched, self.args = model, optimizer, scheduler, args
+        self.static = None            # {"unsup": [...], "sup": [...], "disc": [...]} of 4-tuples of device tensors
+        self.sig = None
+        self.graphs = {}              # signature -> _Captured
+        self.pending_lr = None        # learning rate of the D phase that has not run yet (None: nothing pending)
+        self.warmed = set()           # signatures whose shifted body has run eagerly once
+        self.epoch = 0
+        ops.step_state()              # device block + RNG-epoch pointer exist before any capture
+
+    # ---- plumbing ------------------------------------------------------------------------------------------------
+    def capturable(self):
+        return getattr(self.args, "cm_steps", 0) == 0 and not ddp.active()
+
+    def _signature(self, batches):
+        a = self.args
+        keys = [("unsup", a.ae_steps), ("sup", a.sp_steps)] + ([("disc", a.d_steps)] if a.use_discriminator else [])
+        sig = tuple((k, i, tuple(tuple(t.shape) for t in batches[k][i])) for k, n in keys for i in range(n))
+        return sig + (is_deterministic(), config.NSPLIT, self.model.training)
+
+    def _load(self, batches, keys):
+        """Copies the batches into the static input buffers (device-to-device or host-to-device on the current stream)."""
+        dev = T._dev()
+        if self.static is None or self.sig != self._signature(batches):
+            assert self.pending_lr is None
+            self.sig = self._signature(batches)
+            self.static = {}
+            a = self.args
+            for k, n in (("unsup", a.ae_steps), ("sup", a.sp_steps), ("disc", a.d_steps if a.use_discriminator else 0)):
+                self.static[k] = [tuple(torch.empty(t.shape, dtype=t.dtype, device=dev) for t in batches[k][i]) for i in range(n)]
+        for k in keys:
+            for dst, src in zip(self.static[k], batches[k]):
+                for d, s in zip(dst, src):
+                    if not (s.is_cuda and s.data_ptr() == d.data_ptr()):
+                        d.copy_(s, non_blocking=True)
+
+    def _gen_phase(self, losses):
+        a, model = self.args, self.model
+        if a.use_discriminator:
+            T.freeze_model_parameters(model.discriminator)
+        accum = a.ae_steps + a.sp_steps
+        subs = [(T.train_ae_step, b) for b in self.static["unsup"]] + [(T.train_sp_step, b) for b in self.static["sup"]]
+        for fn, b in subs:
+            fn(losses, model, b, 0, accum, a)
+        T.optimizer_step(model, self.opt, a)
+
+    def _d_phase(self, losses, defer):
+        a, model = self.args, self.model
+        T.unfreeze_model_parameters(model.discriminator)
+        for b in self.static["disc"]:
+            T.train_discriminator_step(losses, model, b, 0, a.d_steps, a, defer=defer)
+        T.optimizer_step(model, self.opt, a, defer=defer)
+
+    def _body(self, losses):
+        """[ D phase of the previous step || generator phase of this step ], all streams joined at the end."""
+        if self.args.use_discriminator:
+            self._d_phase(losses, defer=True)
+        self._gen_phase(losses)
+        join_streams()
+
+    # ---- the step ------------------------------------------------------------------------------------------------
+    def __call__(self, losses, batches, step=0):
+        a, model, opt = self.args, self.model, self.opt
+        if not self.capturable():
+            T.train_step(losses, model, opt, self.sched, batches, step, a, defer_d_phase=True)
+            return
+        if not model.training:
+            model.train()
+        model._store().sync_split()                       # parameters written through torch since the last step?
+        if self.sig is not None and self.pending_lr is not None and self._signature(batches) != self.sig:
+            self.flush(losses)                            # other input shapes: the pending D phase still belongs to the old buffers
+        lr_now = float(opt.param_groups[0]["lr"])
+        if a.use_discriminator and self.pending_lr is None:
+            # first step (or first after flush()): generator phase only, eagerly; its D phase runs inside the next call
+            self._load(batches, ("unsup", "sup", "disc"))
+            self._gen_phase(losses)
+            join_streams()
+        else:
+            self._load(batches, ("unsup", "sup"))          # "disc" still holds the previous step's batch: the body reads it first
+            sig = self.sig
+            rec = self.graphs.get(sig)
+            if rec is None and sig not in self.warmed:
+                # once eagerly with exactly the body's call sequence (lazy initialisations, allocator warm-up, stream creation)
+                self._with_lrs(lambda: self._body(losses), lr_now)
+                self.warmed.add(sig)
+            else:
+                if rec is None:
+                    rec = self._capture(sig)
+                self._replay(rec, losses, lr_now)
+            if a.use_discriminator:
+                self._load(batches, ("disc",))             # ordered behind the replay that read the previous one
+        if a.use_discriminator:
+            self.pending_lr = lr_now
+        if self.sched is not None:
+            self.sched.step()
+
+    def _with_lrs(self, fn, lr_now):
+        """Eager run of the shifted body: the D phase of the previous step uses the previous step's learning rate."""
+        g = self.opt.param_groups[0]
+        if not self.args.use_discriminator:
+            return fn()
+        # the body is D phase then generator phase; switch lr between them by wrapping the optimizer's step
+        seen = {"n": 0}
+        orig = self.opt.step
+
+        def step(*aa, **kk):
+            g["lr"] = self.pending_lr if seen["n"] == 0 else lr_now
+            seen["n"] += 1
+            return orig(*aa, **kk)
+        self.opt.step = step
+        try:
+            return fn()
+        finally:
+            self.opt.step = orig
+            g["lr"] = lr_now
+
+    def _capture(self, sig):
+        from .inference import _capture
+        if len(self.graphs) >= MAX_GRAPHS:
+            self.graphs.pop(next(iter(self.graphs)))
+        join_streams()
+        torch.cuda.synchronize()
+        rec = _Captured()
+        cap_losses = defaultdict(list)
+        self.opt.captured_ranges = []
+        sync_flag, T.SYNC_LOSSES = T.SYNC_LOSSES, False
+
+        def fn():
+            self._body(cap_losses)
+            flat = [(k, v) for k, vs in cap_losses.items() for v in vs]
+            rec.loss_keys = [k for k, _ in flat]
+            rec.loss_vec = torch.stack([v.reshape(()) for _, v in flat]) if flat else None
+        try:
+            rec.graph = _capture(fn)
+        finally:
+            T.SYNC_LOSSES = sync_flag
+        rec.ranges = list(self.opt.captured_ranges)
+        self.graphs[sig] = rec
+        return rec
+
+    def _replay(self, rec, losses, lr_now):
+        hyper = {}
+        dr = self.model._store().regions.get("disc")
+        for rng in rec.ranges:
+            lr = self.pending_lr if (self.args.use_discriminator and rng == dr) else lr_now
+            slot, vals = self.opt.replay_hyper(rng, lr)
+            hyper[slot] = vals
+        self.epoch += 1
+        ops.set_step_state(self.epoch, hyper)
+        rec.graph.replay()
+        self.opt._step_count = getattr(self.opt, "_step_count", 0) + 1       # what torch's LR schedulers look at
+        if rec.loss_vec is not None:
+            snap = rec.loss_vec.clone()
+            for i, k in enumerate(rec.loss_keys):
+                losses[k].append(snap[i])
+
+    def flush(self, losses=None):
+        """Runs the discriminator phase that is still pending (eagerly, joined): before evaluation, checkpoints, or reading
+        parameters."""
+        if self.pending_lr is None:
+            join_streams()
+            return
+        losses = losses if losses is not None else defaultdict(list)
+        g = self.opt.param_groups[0]
+        lr_now = g["lr"]
+        g["lr"] = self.pending_lr
+        try:
+            self._d_phase(losses, defer=False)
+        finally:
+            g["lr"] = lr_now
+        T.freeze_model_parameters(self.model.discriminator)
+        join_streams()
+        self.pending_lr = None

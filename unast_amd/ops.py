@@ -399,6 +399,12 @@ def disc_targets(perm, B, flip, out, smoothing=0.1):
     check(lib().unast_disc_targets(_p(perm), perm.numel(), B, int(flip), smoothing, _p(out), _stream()), "unast_disc_targets")
 
 
+def randperm(n, seed, stream_id, device):
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    check(lib().unast_randperm(_p(out), n, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_randperm")
+    return out
+
+
 def bce_logits(logits, ldx, targets, n, loss=None, gscale=None, dlogits=None, ldd=1):
     check(lib().unast_bce_logits(_p(logits), ldx, _p(targets), n, _p(gscale), _p(loss), _p(dlogits), ldd, _stream()), "unast_bce_logits")
 
@@ -434,22 +440,60 @@ def adamw(p, g, m, v, sumsq_scalar, max_norm, lr, beta1, beta2, eps, wd, step, s
                             _p(split_out), int(bool(decoupled)), _p(dev_hyper), _stream()), "unast_adamw")
 
 
+def adam_hyper(lr, beta1, beta2, step):
+    """The three floats unast_adamw derives from (lr, step) on the host -- {lr, 1 - beta1^t, sqrt(1 - beta2^t)} with the betas
+    rounded to fp32 first, as the C entry point receives them -- for the device-resident block a captured step reads."""
+    import ctypes
+    import math
+    b1, b2 = ctypes.c_float(beta1).value, ctypes.c_float(beta2).value
+    return [float(lr), 1.0 - b1 ** int(step), math.sqrt(1.0 - b2 ** int(step))]
+
+
 def split_f32(src, dst):
     """dst = src in the GEMM's pre-split operand format (16-B chunks [hi x4 | lo x4] of bf16; same byte offsets)."""
     check(lib().unast_split_f32(_p(src), _p(dst), src.numel(), _stream()), "unast_split_f32")
 
 
-_RNG_EPOCH = {}
+_STEP_STATE = {}
+STEP_STATE_WORDS = 64
+
+
+def step_state():
+    """Per-device block of 64 32-bit words in device memory that captured (HIP-graph) work reads at replay time:
+    word 0 = the RNG epoch mixed into every dropout / noise stream (unast_set_rng_epoch), words 4.. = float triples
+    {lr, 1 - beta1^t, sqrt(1 - beta2^t)} for unast_adamw's dev_hyper.  One small host-to-device copy refreshes all of it."""
+    dev = torch.cuda.current_device()
+    c = _STEP_STATE.get(dev)
+    if c is None:
+        torch.cuda.synchronize()
+        c = torch.zeros(STEP_STATE_WORDS, dtype=torch.int32, device="cuda:%d" % dev)
+        torch.cuda.synchronize()
+        check(lib().unast_set_rng_epoch(c.data_ptr()), "unast_set_rng_epoch")
+        _STEP_STATE[dev] = c
+    return c
 
 
 def rng_epoch_counter():
     """The device counter mixed into every dropout / noise stream (unast_set_rng_epoch): int32 [1], 0 outside graph replay."""
-    dev = torch.cuda.current_device()
-    c = _RNG_EPOCH.get(dev)
-    if c is None:
-        torch.cuda.synchronize()
-        c = torch.zeros(1, dtype=torch.int32, device="cuda:%d" % dev)
-        torch.cuda.synchronize()
-        check(lib().unast_set_rng_epoch(c.data_ptr()), "unast_set_rng_epoch")
-        _RNG_EPOCH[dev] = c
-    return c
+    return step_state()[0:1]
+
+
+def set_step_state(epoch, hyper_by_slot):
+    """One tiny launch: RNG epoch (word 0) and the hyper-parameter triples {slot: [lr, bc1, bc2_sqrt]} (words 4 + 3*slot ..)."""
+    import ctypes
+    import struct
+    words = (ctypes.c_uint * 16)()
+    words[0] = epoch & 0xFFFFFFFF
+    n = 4
+    for slot, vals in hyper_by_slot.items():
+        if 4 + 3 * slot + 3 > 16:
+            raise ValueError("set_step_state: at most 4 optimizer ranges")
+        for j, v in enumerate(vals):
+            words[4 + 3 * slot + j] = struct.unpack("<I", struct.pack("<f", float(v)))[0]
+        n = max(n, 4 + 3 * slot + 3)
+    check(lib().unast_set_words(_p(step_state()), ctypes.cast(words, ctypes.c_void_p), n, _stream()), "unast_set_words")
+
+
+def hyper_slot(i):
+    """float32 [3] view of the i-th optimizer hyper-parameter triple inside step_state()."""
+    return step_state().view(torch.float32)[4 + 3 * i: 7 + 3 * i]

@@ -27,7 +27,7 @@ from . import ddp, ops
 from .engine import Var, run_segment, on_stream, side_streams, join_streams, stream_of, join_wgrad_streams
 from .network import TextTransformer, SpeechTransformer, UNAST, Discriminator, LSTMDiscriminator, _as_padded
 from .utils import (PAD_IDX, SOS_IDX, EOS_IDX, lens_i32, specaugment, sent_lens_to_mask, get_teacher_ratio, is_deterministic,
-                    set_seed)  # noqa: F401
+                    set_seed, next_seed)  # noqa: F401
 
 DEVICE = None
 WRITER = None
@@ -267,7 +267,7 @@ def discriminator_shuffle_batch(t_hid, t_hid_len, s_hid, s_hid_len, model_type, 
     Ts = s_hid.shape[1]
     Tmax = max(Tt, Ts)
     dev = t_hid.device
-    perm = torch.arange(2 * B, device=dev) if is_deterministic() else torch.randperm(2 * B, device=dev)
+    perm = torch.arange(2 * B, device=dev) if is_deterministic() else ops.randperm(2 * B, next_seed(), 1, dev)
     tl, sl = lens_i32(t_hid_len, dev), lens_i32(s_hid_len, dev)
     d_len = torch.empty(2 * B, dtype=torch.int32, device=dev)
     d_target = torch.empty(2 * B, dtype=torch.float32, device=dev)
@@ -657,6 +657,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._steps = defaultdict(int)
         self._ss = None
         self.last_grad_norm_sq = None
+        self._slots = {}                 # gradient range -> index of its hyper-parameter triple in ops.step_state()
+        self.captured_ranges = []        # ranges stepped while a HIP graph was being captured, in order
 
     def _buffers(self, st):
         if self._m is None or self._m.device != st.flat.device or self._m.numel() != st.total:
@@ -683,11 +685,28 @@ class FusedAdamW(torch.optim.Optimizer):
         for a, b in ranges:
             ops.sumsq(st.grad[a:b], self._ss)
         self.last_grad_norm_sq = self._ss
+        capturing = torch.cuda.is_current_stream_capturing()
         for a, b in ranges:
+            if capturing:
+                # Recorded into a HIP graph (unast_amd.graphed): the learning rate and the bias corrections are read from device
+                # memory at replay time; the host-side step count of this range advances per replay (replay_hyper).
+                slot = self._slots.setdefault((a, b), len(self._slots))
+                ops.adamw(st.flat[a:b], st.grad[a:b], self._m[a:b], self._v[a:b], self._ss, float(max_norm), 0.0,
+                          g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], 0, split_out=st.flat_split[a:b],
+                          decoupled=self.decoupled, dev_hyper=ops.hyper_slot(slot))
+                self.captured_ranges.append((a, b))
+                continue
             self._steps[(a, b)] += 1
             ops.adamw(st.flat[a:b], st.grad[a:b], self._m[a:b], self._v[a:b], self._ss, float(max_norm), float(g["lr"]),
                       g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps[(a, b)], split_out=st.flat_split[a:b],
                       decoupled=self.decoupled)
+
+    def replay_hyper(self, rng, lr):
+        """Host side of one replay of a captured step for the range `rng`: advances its step count and returns
+        (slot, [lr, 1 - beta1^t, sqrt(1 - beta2^t)]) for the device block the captured AdamW launch reads."""
+        self._steps[rng] += 1
+        g = self.param_groups[0]
+        return self._slots[rng], ops.adam_hyper(lr, g["betas"][0], g["betas"][1], self._steps[rng])
 
     def zero_grad(self, set_to_none=True):
         self.model._store().zero_grad()
