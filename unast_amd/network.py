@@ -100,6 +100,22 @@ def _out3d(tape, var2d, B, T):
     return o
 
 
+def _alias(tape, var):
+    """A second output of the same activation (a view) for a second consumer.  Each of the two then has exactly one user in
+    torch's autograd graph and THIS call's backward adds the two incoming gradients itself (on its own stream, after autograd
+    has ordered it behind both producers).  Letting autograd sum gradients that arrive from different streams in a node's
+    input buffer works eagerly but takes hipStreamEndCapture down when the step is captured into a HIP graph (ROCm 7.2;
+    tools/debug_capture.py cases aedisc_* vs discdetach_ms), and the encoder output has two users on two streams: the
+    decoder (cross-attention memory) and the discriminator."""
+    o = Var(var.v.view(var.v.shape))
+    if tape is not None:
+        def bwd():
+            if o.g is not None:
+                acc(var, o.g if o.g.is_contiguous() else o.g.contiguous())
+        tape.record(bwd)                                   # recorded after var's own closure => runs before it
+    return o
+
+
 def _mem_in(tape, mem, B, Tk):
     """[B,Tk,E] input Var -> [B*Tk,E] Var; its closure (recorded first => runs last) hands the gradient back."""
     memv = Var(mem.v.contiguous().view(B * Tk, -1))
@@ -135,9 +151,10 @@ class TextTransformer(AutoEncoderNet):
         ids = input_.contiguous()
 
         def run(tape, dummy):
-            return [_out3d(tape, F.text_encode(cx, tape, self, ids, lens, noise_in), B, T)]
-        enc = run_segment(run, ddp_hook("text_enc", cx.st), cx.st.dummy)
-        return enc, (None, lens)
+            o = _out3d(tape, F.text_encode(cx, tape, self, ids, lens, noise_in), B, T)
+            return [o, _alias(tape, o)]
+        enc, enc_hid = run_segment(run, ddp_hook("text_enc", cx.st), cx.st.dummy)
+        return enc, (None, lens, enc_hid)
 
     @on_stream("text")
     def decode_sequence(self, tgt, tgt_lens, enc_outputs, masks, teacher_ratio=1):
@@ -169,7 +186,7 @@ class TextTransformer(AutoEncoderNet):
         enc_outputs, masks = self.encode(text, text_len, noise_in)
         dec_out = self.decode_sequence(text, text_len, enc_outputs, masks)
         if ret_enc_hid:
-            return dec_out, enc_outputs
+            return dec_out, masks[2]                       # the encoder output once more, for its second user (see _alias)
         return dec_out
 
     def infer_sequence(self, memory, masks, max_len=300):
@@ -210,9 +227,10 @@ class SpeechTransformer(AutoEncoderNet):
         mel = input_.detach().contiguous()
 
         def run(tape, dummy):
-            return [_out3d(tape, F.speech_encode(cx, tape, self, mel, lens, noise_in), B, T)]
-        enc = run_segment(run, ddp_hook("speech_enc", cx.st), cx.st.dummy)
-        return enc, (None, lens)
+            o = _out3d(tape, F.speech_encode(cx, tape, self, mel, lens, noise_in), B, T)
+            return [o, _alias(tape, o)]
+        enc, enc_hid = run_segment(run, ddp_hook("speech_enc", cx.st), cx.st.dummy)
+        return enc, (None, lens, enc_hid)
 
     @on_stream("speech")
     def decode_sequence(self, tgt, tgt_lens, enc_outputs, masks, teacher_ratio=1):
@@ -258,7 +276,7 @@ class SpeechTransformer(AutoEncoderNet):
         enc_outputs, masks = self.encode(mel, mel_len, noise_in)
         pre_pred, post_pred, stop_pred, stop_lens = self.decode_sequence(mel, mel_len, enc_outputs, masks)
         if ret_enc_hid:
-            return pre_pred, post_pred, stop_pred, enc_outputs
+            return pre_pred, post_pred, stop_pred, masks[2]
         return pre_pred, post_pred, stop_pred
 
     def infer_sequence(self, memory, masks, max_len=815):
@@ -418,7 +436,7 @@ class UNAST(_Side):
         else:
             pre_pred, post_pred, stop_pred, stop_lens = self.speech_m.infer_sequence(t_e_o, t_masks)
         if ret_enc_hid:
-            return pre_pred, post_pred, stop_pred, stop_lens, t_e_o
+            return pre_pred, post_pred, stop_pred, stop_lens, t_masks[2]
         return pre_pred, post_pred, stop_pred, stop_lens
 
     def asr(self, text, text_len, mel, mel_len, infer=False, ret_enc_hid=False):
@@ -428,7 +446,7 @@ class UNAST(_Side):
         else:
             text_pred = self.text_m.infer_sequence(s_e_o, s_masks)
         if ret_enc_hid:
-            return text_pred, s_e_o
+            return text_pred, s_masks[2]
         return text_pred
 
     def tts_and_asr(self, text, text_len, mel, mel_len, mel_aug, ret_enc_hid=False):
@@ -442,7 +460,7 @@ class UNAST(_Side):
         pre_pred, post_pred, stop_pred, stop_lens = self.speech_m.decode_sequence(mel, mel_len, t_e_o, t_masks, teacher_ratio=1)
         text_pred = self.text_m.decode_sequence(text, text_len, s_e_o, s_masks, teacher_ratio=1)
         if ret_enc_hid:
-            return (pre_pred, post_pred, stop_pred, stop_lens, t_e_o), (text_pred, s_e_o)
+            return (pre_pred, post_pred, stop_pred, stop_lens, t_masks[2]), (text_pred, s_masks[2])
         return (pre_pred, post_pred, stop_pred, stop_lens), text_pred
 
     def cm_text_in(self, text, text_len, ret_enc_hid=False):
@@ -453,7 +471,7 @@ class UNAST(_Side):
         cm_s_e_o, cm_mask = self.speech_m.encode(post_pred.detach(), pred_lens.detach())
         text_pred = self.text_m.decode_sequence(text, text_len, cm_s_e_o, cm_mask, teacher_ratio=1)
         if ret_enc_hid:
-            return text_pred, cm_s_e_o, pred_lens
+            return text_pred, cm_mask[2], pred_lens
         return text_pred
 
     def cm_speech_in(self, mel, mel_len, ret_enc_hid=False):
@@ -464,7 +482,7 @@ class UNAST(_Side):
         cm_t_e_o, cm_t_masks = self.text_m.encode(text_pred.detach(), text_pred_len.detach())
         pre_pred, post_pred, stop_pred, stop_lens = self.speech_m.decode_sequence(mel, mel_len, cm_t_e_o, cm_t_masks, teacher_ratio=1)
         if ret_enc_hid:
-            return pre_pred, post_pred, stop_pred, cm_t_e_o, text_pred_len
+            return pre_pred, post_pred, stop_pred, cm_t_masks[2], text_pred_len
         return pre_pred, post_pred, stop_pred
 
     def cm_both_in(self, text, text_len, mel, mel_len, ret_enc_hid=False):
@@ -482,7 +500,7 @@ class UNAST(_Side):
         cm_s_e_o, cm_mask = self.speech_m.encode(post_pred.detach(), pred_lens.detach())
         text_out = self.text_m.decode_sequence(text, text_len, cm_s_e_o, cm_mask, teacher_ratio=1)
         if ret_enc_hid:
-            return (pre_pred, post_pred_s, stop_pred, cm_t_e_o, text_pred_len), (text_out, cm_s_e_o, pred_lens)
+            return (pre_pred, post_pred_s, stop_pred, cm_t_masks[2], text_pred_len), (text_out, cm_mask[2], pred_lens)
         return (pre_pred, post_pred_s, stop_pred), text_out
 
     def num_params(self):
