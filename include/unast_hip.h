@@ -213,6 +213,23 @@ int unast_leaky_dropout(const float* x, const float* dy, float* out, int rows, i
  * Blocking (hipMemcpyToSymbol); call it while no kernel of this library is in flight. */
 int unast_set_rng_epoch(const unsigned int* counter);
 
+/* Several weight gradients of one backward closure in ONE launch (+ one reduction): for each problem
+ * C[M,N] += A[tokens,M]^T B[tokens,N] (A = dY, B = X of an nn.Linear, src/module.py:18-39 / torch's TransformerEncoder/DecoderLayer
+ * linears) and, if rowsum_a != NULL, rowsum_a[M] += column sums of A (the bias gradient).  Stands where torch's autograd
+ * issues one addmm per weight in loss.backward() (src/train.py:380, 401).  count <= 8.  ws: caller-owned slab workspace of
+ * unast_wgrad_group_ws_floats(...) floats; target_blocks (0 = 512) = workgroups to aim for when cutting the token reduction
+ * into K-slices. */
+typedef struct {
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    float* rowsum_a;
+    int M, N, K;
+} unast_wgrad_item;
+int unast_wgrad_group(int nsplit, int count, const unast_wgrad_item* items, float* ws, int64_t ws_floats, int target_blocks,
+                      hipStream_t stream);
+int64_t unast_wgrad_group_ws_floats(int count, const unast_wgrad_item* items, int target_blocks);
+
 /* optimizer_step (src/train.py:358-363): clip_grad_norm_ + torch.optim.AdamW (decoupled = 1) or torch.optim.Adam with L2
  * weight decay (decoupled = 0; optim_type 'adam', src/train.py:929-930) over flat fp32 buffers.
  * dev_hyper (may be NULL): three floats in device memory {lr, 1 - beta1^t, sqrt(1 - beta2^t)} that replace lr / step, so a

@@ -192,3 +192,67 @@ def test_tile_variants_agree_bitwise(nsplit, M, N, K):
     for o in outs[1:]:
         assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])
     config.NSPLIT = 3
+
+
+@pytest.mark.parametrize("nsplit", [3, 1])
+def test_grouped_weight_gradients_match_fp64_and_single_launches(nsplit):
+    """unast_wgrad_group: the weight (and bias) gradients of several linears -- different shapes, different token counts, one
+    of them accumulating into a non-zero buffer -- from ONE launch, against fp64 and against the one-by-one split-K path."""
+    from unast_amd import ops, config
+    config.NSPLIT = nsplit
+    g = torch.Generator().manual_seed(21)
+    probs = [(25600, 256, 256), (25600, 768, 256), (5760, 512, 256), (4096, 256, 1024), (4096, 1024, 256)]      # (tokens, out, in)
+    data = []
+    for (M, N, K) in probs:
+        dy = torch.randn(M, N, generator=g).to(dev()); x = torch.randn(M, K, generator=g).to(dev())
+        dW0 = torch.randn(N, K, generator=g).to(dev()); db0 = torch.randn(N, generator=g).to(dev())
+        data.append((dy, x, dW0, db0))
+    outs = []
+    for grouped in (True, False):
+        config.WGRAD_GROUP = grouped
+        res = []
+        with ops.wgrad_batch():
+            for dy, x, dW0, db0 in data:
+                dW, db = dW0.clone(), db0.clone()
+                ops.linear_wgrad(dy, x, dW, db=db)
+                res.append((dW, db))
+            if grouped:
+                assert ops._BATCH is not None and len(ops._BATCH) == len(data)       # all five deferred
+        torch.cuda.synchronize()
+        outs.append(res)
+    config.WGRAD_GROUP = True
+    for (dy, x, dW0, db0), (gW, gb), (sW, sb) in zip(data, outs[0], outs[1]):
+        ref = dW0.double().cpu() + dy.double().cpu().t() @ x.double().cpu()
+        assert relerr(gW, ref) < TOL[nsplit] and relerr(sW, ref) < TOL[nsplit]
+        assert relerr(gb, db0.double().cpu() + dy.double().cpu().sum(0)) < 1e-5
+    config.NSPLIT = 3
+
+
+def test_grouped_weight_gradients_general_shapes():
+    """The group entry point on shapes off the interior fast path (rows / columns not multiples of 128, a token count that is
+    not a multiple of 32, strided operand views) -- straight through the C ABI."""
+    import ctypes
+    from unast_amd import ops
+    from unast_amd._lib import lib, check
+    g = torch.Generator().manual_seed(22)
+    probs = [(1000, 192, 320), (777, 46, 256), (2048, 256, 80)]
+    arr = (ops._WgradItem * len(probs))()
+    keep, refs = [], []
+    for j, (M, N, K) in enumerate(probs):
+        ldn, ldk = (N + 3) // 4 * 4 + 8, K + 4
+        dyb = torch.zeros(M, ldn, device=dev()); xb = torch.zeros(M, ldk, device=dev())
+        dy = torch.randn(M, N, generator=g); x = torch.randn(M, K, generator=g)
+        dyb[:, :N] = dy.to(dev()); xb[:, :K] = x.to(dev())
+        dW = torch.zeros(N, K, device=dev()); db = torch.zeros(N, device=dev())
+        a = arr[j]
+        a.A, a.lda, a.B, a.ldb, a.C, a.ldc = dyb.data_ptr(), ldn, xb.data_ptr(), ldk, dW.data_ptr(), K
+        a.rowsum_a, a.M, a.N, a.K = db.data_ptr(), N, K, M
+        keep.append((dyb, xb, dW, db)); refs.append((dy.double().t() @ x.double(), dy.double().sum(0)))
+    ptr = ctypes.cast(arr, ctypes.c_void_p)
+    n = lib().unast_wgrad_group_ws_floats(len(probs), ptr, 0)
+    ws = torch.empty(n, device=dev())
+    check(lib().unast_wgrad_group(3, len(probs), ptr, ws.data_ptr(), n, 0, torch.cuda.current_stream().cuda_stream), "unast_wgrad_group")
+    for (dyb, xb, dW, db), (rW, rb) in zip(keep, refs):
+        assert relerr(dW, rW) < 3e-5 and relerr(db, rb) < 1e-5
+    # too small a workspace is refused, not overrun
+    assert lib().unast_wgrad_group(3, len(probs), ptr, ws.data_ptr(), n - 1, 0, torch.cuda.current_stream().cuda_stream) != 0

@@ -44,3 +44,7 @@ LN_FINALIZE_OFFLOAD = os.environ.get("UNAST_LN_FINALIZE_INLINE", "0") != "1"
 
 # Which logical streams share a real HIP stream ("a:x,b:x" puts a and b on the stream named x).  Experiment switch.
 STREAM_GROUPS = dict(kv.split(":") for kv in os.environ.get("UNAST_STREAM_GROUPS", "").split(",") if ":" in kv)
+
+# Weight gradients of one backward closure (an attention sub-layer's out-proj + in-proj, an FFN's two linears, ...) go out as
+# ONE grouped launch (csrc/gemm.hip gemm_group_kernel) instead of one split-K launch + one reduction each; 0 = one by one.
+WGRAD_GROUP = os.environ.get("UNAST_WGRAD_GROUP", "1") != "0"

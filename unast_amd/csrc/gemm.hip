@@ -14,6 +14,7 @@
 // row-contiguous operands are staged untransposed as [k][row] images and read with ds_read_b64_tr_b16.
 // 256 threads = 4 waves (2x2), each wave owns a 64x64 sub-tile = 4x4 MFMA tiles, accumulators stay in VGPRs.
 #include "common.h"
+#include "../../include/unast_hip.h"
 
 #define GBM 128
 #define GBK 32
@@ -37,6 +38,7 @@ struct GemmParams {
     float* slab; int ld_slab; size_t slab_stride;     // split-K partial slabs [z][M][ld_slab]
     int kb_valid;                                     // rows of a row-contiguous B that exist (K may be zero-padded above it)
     float* rowsum_a;                                  // optional: rowsum_a[m] += sum_k A[m][k] (bias gradient fused into wgrad)
+    int group;                                        // launched as one problem of a grouped weight-gradient launch (split-K tile map, slabs)
 };
 
 __device__ __forceinline__ int swz_h(int row) { return (0x1320 >> (((row >> 2) & 3) << 2)) & 3; }
@@ -184,7 +186,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // FLAGS bit 1 (BSPLIT): B is a weight kept in the pre-split chunk format (common.h split_chunk; written by the AdamW
 //   kernel): the loader copies hi/lo straight to LDS instead of re-splitting the same weights in every row panel.
 template <int AM, int BMODE, int NSPLIT, int WN, int WM, int FLAGS>
-__global__ __launch_bounds__(64 * WM * WN, (WM == 4 ? 4 : 2)) void gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_body(const GemmParams& p, const int pid) {
     constexpr bool FULL = (FLAGS & 1) != 0, BSPLIT = (FLAGS & 2) != 0;
     static_assert(!FULL || ((AM == OP_KC || AM == OP_RC) && (BMODE == OP_KC || BMODE == OP_RC)), "FULL: plain operands only");
     constexpr bool A_KC = (AM == OP_KC || AM == OP_KC_CONV);
@@ -205,9 +207,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 ? 4 : 2)) void gemm_kernel(c
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];      // two stages: one barrier per k-step
 
     // XCD-aware tile mapping: blocks b and b+8 (same XCD under round-robin dispatch) share the A row panel.
-    const int pid = blockIdx.x;
     int tile_m, tile_n, zsplit = 0;
-    if (p.tiles_m >= 8 && p.nsplitk == 1) {
+    if (p.tiles_m >= 8 && p.nsplitk == 1 && !p.group) {
         const int G = 8 * p.tiles_n;
         const int grp = pid / G, rem = pid - grp * G;
         tile_m = grp * 8 + (rem & 7);
@@ -395,6 +396,88 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 ? 4 : 2)) void gemm_kernel(c
     gemm_epilogue<MI>(p, acc, m0, n0, wm, wn, l15, g, zsplit);
 }
 
+template <int AM, int BMODE, int NSPLIT, int WN, int WM, int FLAGS>
+__global__ __launch_bounds__(64 * WM * WN, (WM == 4 ? 4 : 2)) void gemm_kernel(const GemmParams p) {
+    gemm_body<AM, BMODE, NSPLIT, WN, WM, FLAGS>(p, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped weight gradients: up to GROUP_MAX problems dW_i[M_i,N_i] += dY_i^T X_i of one backward closure (the out-proj and
+// in-proj gradients of an attention sub-layer, the two FFN gradients, ...) in ONE launch.  A 256x256 gradient over 25 600
+// tokens is 4 output tiles: launched alone it needs 64 K-slices of 12 k-steps to fill the chip and three quarters of its time
+// is fixed cost (prologue, epilogue, 16.8 MB of partial slabs written and re-read).  Grouped, the problems share the
+// chip: each workgroup runs 50-100 k-steps and a layer's slab traffic falls from 118 MB to ~25 MB.  Every workgroup maps its block
+// id to (problem, tile, K-slice), builds that problem's GemmParams in scalar registers and runs the same body as gemm_kernel;
+// partial sums go to slabs, a grouped reduction adds them into the gradient buffers.
+// ---------------------------------------------------------------------------------------------
+#define GROUP_MAX 8
+struct GroupItem {
+    const float* A; const float* B; float* C; float* rowsum_a; float* slab;
+    int M, N, K, lda, ldb, ldc;
+    int tiles_m, tiles_n, nsplitk, kchunk, ld_slab;
+};
+struct GroupParams {
+    int count;
+    int base[GROUP_MAX + 1];            // first block id of each problem (GEMM launch)
+    int rbase[GROUP_MAX + 1];           // first block id of each problem (reduction launch)
+    GroupItem it[GROUP_MAX];
+};
+
+template <int NSPLIT, int FLAGS>
+__global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GroupParams gp) {
+    const int b = blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < GROUP_MAX; ++j)
+        if (j < gp.count && b >= gp.base[j]) i = j;
+    const GroupItem& it = gp.it[i];
+    GemmParams p;
+    p.A = it.A; p.B = it.B; p.C = it.C; p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb; p.ldc = it.ldc;
+    p.T = 1; p.ca = 1; p.cb = 1; p.shift = 0; p.KS = 5;
+    p.bias = nullptr; p.R = nullptr; p.ldr = 0; p.G = nullptr; p.ldg = 0; p.gate_scale = 1.f;
+    p.alpha = 1.f; p.beta = 1; p.act = 0; p.drop_thresh = 0u; p.drop_scale = 1.f; p.seed = 0u; p.stream = 0u;
+    p.kchunk = it.kchunk; p.atomic = 0; p.tiles_m = it.tiles_m; p.tiles_n = it.tiles_n; p.nsplitk = it.nsplitk;
+    p.slab = it.slab; p.ld_slab = it.ld_slab; p.slab_stride = (size_t)it.M * it.ld_slab;
+    p.kb_valid = it.K; p.rowsum_a = it.rowsum_a; p.group = 1;
+    gemm_body<OP_RC, OP_RC, NSPLIT, 2, 2, FLAGS>(p, b - gp.base[i]);
+}
+
+// C_i[m][n] += sum_z slab_i[z][m][n] for every problem of a group: 64 float4 elements x 4 slab groups per workgroup, as
+// splitk_reduce_kernel below.
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const GroupParams gp) {
+    __shared__ float4 part[4][64];
+    const int b = blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < GROUP_MAX; ++j)
+        if (j < gp.count && b >= gp.rbase[j]) i = j;
+    const GroupItem& it = gp.it[i];
+    const int nq = it.ld_slab >> 2;
+    const size_t total = (size_t)it.M * nq, slab_stride = (size_t)it.M * it.ld_slab;
+    const int e = threadIdx.x & 63, zg = threadIdx.x >> 6;
+    const size_t idx = (size_t)(b - gp.rbase[i]) * 64 + e;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int m = 0, n = 0;
+    if (idx < total) {
+        m = (int)(idx / nq); n = (int)(idx - (size_t)m * nq) * 4;
+        const float* sp = it.slab + (size_t)m * it.ld_slab + n;
+        for (int z = zg; z < it.nsplitk; z += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(sp + (size_t)z * slab_stride);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    part[zg][e] = a;
+    __syncthreads();
+    if (zg == 0 && idx < total) {
+        const float4 b1 = part[1][e], b2 = part[2][e], b3 = part[3][e];
+        const float av[4] = {(a.x + b1.x) + (b2.x + b3.x), (a.y + b1.y) + (b2.y + b3.y), (a.z + b1.z) + (b2.z + b3.z), (a.w + b1.w) + (b2.w + b3.w)};
+        float* cp = it.C + (size_t)m * it.ldc + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < it.N) cp[r] += av[r];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // What bounds this kernel (MI355X, round-1 measurements; tools/make_gemm_variants.py, tools/make_gemm_stamps.py,
 // tools/mfma_peak.cpp, tools/pmc_gemm.sh; numbers in DESIGN.md section 4):
@@ -527,7 +610,7 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     p.bias = bias; p.R = R; p.ldr = ldr; p.G = G; p.ldg = ldg; p.gate_scale = gate_scale;
     p.alpha = alpha; p.beta = beta; p.act = act;
     p.drop_thresh = drop_threshold(drop_p); p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    p.seed = seed; p.stream = stream_id;
+    p.seed = seed; p.stream = stream_id; p.group = 0;
     // tile width: 128x256 when N is wide enough and the grid still fills the chip; `tile_wn` (2/4) overrides, 0 = auto
     int wn = tile_wn;
     if (wn != 2 && wn != 4 && wn != 8) {
@@ -587,6 +670,85 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p.slab, p.slab_stride, p.ld_slab, splitk, C, ldc, M, N, beta);
     }
     return unast_check_launch("unast_gemm");
+}
+
+// Host side of the grouped weight-gradient launch.  items[i] = {A = dY_i [tokens][M_i] (row stride lda), B = X_i [tokens][N_i],
+// C = dW_i [M_i][N_i] (accumulated into), rowsum_a = db_i or NULL, M, N, K = tokens, lda, ldb, ldc}.
+extern "C" int unast_wgrad_group(int nsplit, int count, const unast_wgrad_item* items, float* ws, int64_t ws_floats, int target_blocks,
+                                 hipStream_t stream) {
+    UNAST_REQUIRE(items && count >= 1 && count <= GROUP_MAX, "unast_wgrad_group: 1..%d problems per launch (got %d)", GROUP_MAX, count);
+    UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_wgrad_group: nsplit must be 1 or 3");
+    UNAST_REQUIRE(ws && ((((uintptr_t)ws) & 15) == 0), "unast_wgrad_group: needs a 16-byte aligned slab workspace");
+    if (target_blocks <= 0) target_blocks = 512;
+    GroupParams gp;
+    gp.count = count;
+    bool full = true;
+    long long tile_ksteps = 0;
+    for (int i = 0; i < count; ++i) {
+        const unast_wgrad_item& s = items[i];
+        UNAST_REQUIRE(s.A && s.B && s.C && s.M > 0 && s.N > 0 && s.K > 0, "unast_wgrad_group: bad problem %d", i);
+        UNAST_REQUIRE(aligned16(s.A) && aligned16(s.B) && aligned16(s.C) && (s.lda & 3) == 0 && (s.ldb & 3) == 0, "unast_wgrad_group: problem %d: operands must be 16-byte aligned with ld %% 4 == 0", i);
+        UNAST_REQUIRE(s.lda >= ((s.M + 3) & ~3) && s.ldb >= ((s.N + 3) & ~3), "unast_wgrad_group: problem %d: row-contiguous operands need ld >= ceil4(rows)", i);
+        GroupItem& it = gp.it[i];
+        it.A = s.A; it.B = s.B; it.C = s.C; it.rowsum_a = s.rowsum_a; it.M = s.M; it.N = s.N; it.K = s.K; it.lda = s.lda; it.ldb = s.ldb; it.ldc = s.ldc;
+        it.tiles_m = (s.M + GBM - 1) / GBM; it.tiles_n = (s.N + 127) / 128;
+        it.ld_slab = (s.N + 3) & ~3;
+        const uint64_t a_span = (uint64_t)(GBK + 1) * s.lda * 4 + (uint64_t)s.M * 4, b_span = (uint64_t)(GBK + 1) * s.ldb * 4 + (uint64_t)s.N * 4;
+        if (!(s.M % GBM == 0 && s.N % 128 == 0 && s.K % GBK == 0 && a_span < (1ull << 32) && b_span < (1ull << 32))) full = false;
+        tile_ksteps += (long long)it.tiles_m * it.tiles_n * ((s.K + GBK - 1) / GBK);
+    }
+    // K-slices: every workgroup gets about the same number of k-steps (at least 10), ~target_blocks workgroups in all
+    long long per_wg = (tile_ksteps + target_blocks - 1) / target_blocks;
+    if (per_wg < 10) per_wg = 10;
+    size_t ws_need = 0;
+    int blocks = 0, rblocks = 0;
+    for (int i = 0; i < count; ++i) {
+        GroupItem& it = gp.it[i];
+        const int ksteps = (it.K + GBK - 1) / GBK;
+        int splits = (int)((ksteps + per_wg - 1) / per_wg);
+        if (splits < 1) splits = 1;
+        const int steps_per = (ksteps + splits - 1) / splits;
+        it.kchunk = steps_per * GBK;
+        it.nsplitk = (ksteps + steps_per - 1) / steps_per;
+        it.slab = ws + ws_need;
+        ws_need += (size_t)it.nsplitk * it.M * it.ld_slab;
+        gp.base[i] = blocks;
+        blocks += ((it.nsplitk + 7) / 8) * 8 * it.tiles_m * it.tiles_n;
+        gp.rbase[i] = rblocks;
+        rblocks += (int)(((size_t)it.M * (it.ld_slab / 4) + 63) / 64);
+    }
+    for (int i = count; i <= GROUP_MAX; ++i) { gp.base[i] = blocks; gp.rbase[i] = rblocks; }
+    UNAST_REQUIRE((int64_t)ws_need <= ws_floats, "unast_wgrad_group: workspace too small (need %lld floats, got %lld)", (long long)ws_need, (long long)ws_floats);
+    if (nsplit == 3) {
+        if (full) hipLaunchKernelGGL((gemm_group_kernel<3, 1>), dim3(blocks), dim3(256), 0, stream, gp);
+        else      hipLaunchKernelGGL((gemm_group_kernel<3, 0>), dim3(blocks), dim3(256), 0, stream, gp);
+    } else {
+        if (full) hipLaunchKernelGGL((gemm_group_kernel<1, 1>), dim3(blocks), dim3(256), 0, stream, gp);
+        else      hipLaunchKernelGGL((gemm_group_kernel<1, 0>), dim3(blocks), dim3(256), 0, stream, gp);
+    }
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rblocks), dim3(256), 0, stream, gp);
+    return unast_check_launch("unast_wgrad_group");
+}
+
+// Floats of slab workspace unast_wgrad_group needs for these problems (same split policy).
+extern "C" int64_t unast_wgrad_group_ws_floats(int count, const unast_wgrad_item* items, int target_blocks) {
+    if (!items || count < 1 || count > GROUP_MAX) return -1;
+    if (target_blocks <= 0) target_blocks = 512;
+    long long tile_ksteps = 0;
+    for (int i = 0; i < count; ++i)
+        tile_ksteps += (long long)((items[i].M + GBM - 1) / GBM) * ((items[i].N + 127) / 128) * ((items[i].K + GBK - 1) / GBK);
+    long long per_wg = (tile_ksteps + target_blocks - 1) / target_blocks;
+    if (per_wg < 10) per_wg = 10;
+    int64_t need = 0;
+    for (int i = 0; i < count; ++i) {
+        const int ksteps = (items[i].K + GBK - 1) / GBK;
+        int splits = (int)((ksteps + per_wg - 1) / per_wg);
+        if (splits < 1) splits = 1;
+        const int steps_per = (ksteps + splits - 1) / splits;
+        const int ns = (ksteps + steps_per - 1) / steps_per;
+        need += (int64_t)ns * items[i].M * ((items[i].N + 3) & ~3);
+    }
+    return need;
 }
 
 UNAST_DEFINE_RNG_EPOCH_SETTER(gemm)

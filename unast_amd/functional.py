@@ -93,6 +93,10 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
         def bwd():
             if out.g is None:
                 return
+            with ops.wgrad_batch():            # out-proj + in-proj weight gradients: one grouped launch at the end
+                bwd_body()
+
+        def bwd_body():
             st = cx.st
             dz = _empty(Nq, E, like=z)
             dzd = _empty(Nq, E, like=z) if p > 0 else None
@@ -151,6 +155,10 @@ def ffn_sublayer(cx, tape, x, pre, pre_norm, drop):
         def bwd():
             if out.g is None:
                 return
+            with ops.wgrad_batch():            # linear2 + linear1 weight gradients: one grouped launch at the end
+                bwd_body()
+
+        def bwd_body():
             st = cx.st
             dz = _empty(N, E, like=z)
             dzd = _empty(N, E, like=z) if p > 0 else None
@@ -514,6 +522,10 @@ def lstm_discriminator(cx, tape, m, x, lens, Bd, T, need_input_grad=True):
         def bwd():
             if out.g is None:
                 return
+            with ops.wgrad_batch():            # the input-projection gradients of both LSTM layers: one grouped launch
+                bwd_body()
+
+        def bwd_body():
             dl = out.g                                             # [Bd,4], column 0 valid
             g2 = st.g("discriminator.fc2.weight")
             if g2 is not None:

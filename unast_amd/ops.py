@@ -148,14 +148,115 @@ def _on_wgrad_stream(launch, tokens, key, *operands):
         return launch()
 
 
-def linear_wgrad(dy2d, x2d, dW, db=None):
-    """dW[N,K] += dy2d[M,N]^T @ x2d[M,K]; optionally db[N] += sum_rows dy2d (fused).  Always accumulates."""
+def _linear_wgrad_now(dy2d, x2d, dW, db=None):
     M, N = dy2d.shape
     K = x2d.shape[1]
     sk = _splitk_for(N, K, M)
     _on_wgrad_stream(lambda: gemm(OP_RC, OP_RC, dy2d, dy2d.stride(0), x2d, x2d.stride(0), dW, dW.stride(0), N, K, M, beta=1, splitk=sk,
                                   rowsum_a=db), M, dW.data_ptr(), dy2d, x2d)
     return dW
+
+
+import ctypes as _ct
+
+
+class _WgradItem(_ct.Structure):          # include/unast_hip.h: unast_wgrad_item
+    _fields_ = [("A", _ct.c_void_p), ("lda", _ct.c_int), ("B", _ct.c_void_p), ("ldb", _ct.c_int), ("C", _ct.c_void_p), ("ldc", _ct.c_int),
+                ("rowsum_a", _ct.c_void_p), ("M", _ct.c_int), ("N", _ct.c_int), ("K", _ct.c_int)]
+
+
+_BATCH = None            # list of pending (dy2d, x2d, dW, db) while inside `wgrad_batch()`
+GROUP_MAX = 8
+WGRAD_GROUP_TARGET = int(_os.environ.get("UNAST_WGRAD_GROUP_TARGET", "512"))
+
+
+class wgrad_batch:
+    """While active, eligible weight gradients (linear_wgrad) are collected and issued as ONE grouped launch at exit
+    (unast_wgrad_group): the operands of a backward closure stay alive until it returns, and nobody reads a weight gradient
+    before the optimizer, so deferring them to the closure's end changes no result."""
+
+    def __enter__(self):
+        global _BATCH
+        self.outer = _BATCH is not None
+        if not self.outer and config.WGRAD_GROUP:
+            _BATCH = []
+        return self
+
+    def __exit__(self, *exc):
+        global _BATCH
+        if self.outer or _BATCH is None:
+            return
+        items, _BATCH = _BATCH, None
+        if exc[0] is None:
+            _flush_wgrads(items)
+
+
+def _groupable(dy2d, x2d, dW, db):
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    return (N % 128 == 0 and K % 128 == 0 and M % 32 == 0 and dy2d.stride(1) == 1 and x2d.stride(1) == 1 and dW.stride(1) == 1
+            and dy2d.stride(0) % 4 == 0 and x2d.stride(0) % 4 == 0 and dW.stride(0) % 4 == 0
+            and (dy2d.data_ptr() | x2d.data_ptr() | dW.data_ptr()) % 16 == 0 and M * max(dy2d.stride(0), x2d.stride(0)) < (1 << 29))
+
+
+def _flush_wgrads(items):
+    # the stream choice is per gradient buffer (see _WGRAD_CHOICE): problems bound for the companion stream form one group, the rest another
+    w_side = WGRAD_SIDE() if WGRAD_SIDE is not None else None
+    groups = {}
+    for it in items:
+        dy2d, x2d, dW, db = it
+        key = dW.data_ptr()
+        off = False
+        if w_side is not None:
+            off = _WGRAD_CHOICE.get(key)
+            if off is None:
+                off = _WGRAD_CHOICE[key] = dy2d.shape[0] >= config.WGRAD_STREAM_MIN_TOKENS
+        groups.setdefault(bool(off), []).append(it)
+    for off, its in groups.items():
+        for i in range(0, len(its), GROUP_MAX):
+            chunk = its[i:i + GROUP_MAX]
+            if len(chunk) == 1:
+                _linear_wgrad_now(*chunk[0])
+            else:
+                _launch_group(chunk, off)
+
+
+def _launch_group(chunk, offload):
+    n = len(chunk)
+    arr = (_WgradItem * n)()
+    operands = []
+    for j, (dy2d, x2d, dW, db) in enumerate(chunk):
+        a = arr[j]
+        a.A, a.lda, a.B, a.ldb, a.C, a.ldc = dy2d.data_ptr(), dy2d.stride(0), x2d.data_ptr(), x2d.stride(0), dW.data_ptr(), dW.stride(0)
+        a.rowsum_a = db.data_ptr() if db is not None else None
+        a.M, a.N, a.K = dy2d.shape[1], x2d.shape[1], dy2d.shape[0]
+        operands += [dy2d, x2d]
+    ptr = _ct.cast(arr, _ct.c_void_p)
+    ws_n = lib().unast_wgrad_group_ws_floats(n, ptr, WGRAD_GROUP_TARGET)
+    if ws_n <= 0:
+        raise RuntimeError("unast_wgrad_group_ws_floats failed")
+
+    def launch():
+        ws = torch.empty(ws_n, dtype=torch.float32, device=chunk[0][0].device)
+        check(lib().unast_wgrad_group(config.NSPLIT, n, ptr, _p(ws), ws_n, WGRAD_GROUP_TARGET, _stream()), "unast_wgrad_group")
+    if offload:
+        w = WGRAD_SIDE()
+        w.wait_stream(torch.cuda.current_stream())
+        for t in operands:
+            t.record_stream(w)
+        with torch.cuda.stream(w):
+            launch()
+    else:
+        launch()
+
+
+def linear_wgrad(dy2d, x2d, dW, db=None):
+    """dW[N,K] += dy2d[M,N]^T @ x2d[M,K]; optionally db[N] += sum_rows dy2d (fused).  Always accumulates.  Inside
+    `wgrad_batch()` eligible problems are deferred to the batch's grouped launch."""
+    if _BATCH is not None and _groupable(dy2d, x2d, dW, db):
+        _BATCH.append((dy2d, x2d, dW, db))
+        return dW
+    return _linear_wgrad_now(dy2d, x2d, dW, db)
 
 
 def conv_fwd(x3d, Wp, bias, out, pad_left):
