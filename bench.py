@@ -83,6 +83,8 @@ class OpTimer:
         if n in ("attn_fwd", "attn_bwd"):
             idx = 6 if n == "attn_fwd" else 11
             return tuple(int(x) for x in a[idx:idx + 5])          # B, H, Tq, Tk, causal
+        if n == "wgrad_group":
+            return a[0]                                           # ((out, in, tokens, has_bias), ...)
         return ()
 
     def __exit__(self, *exc):
@@ -113,6 +115,15 @@ def gemm_bytes(key):
     a_el = M * ca if a_mode == 1 else M * K            # OP_KC_CONV: the [B*T, Cin] input
     b_el = K * cb if b_mode == 4 else N * K            # OP_RC_CONV_WGRAD: the [B*T, Cin] input
     return 4.0 * (a_el + b_el + M * N * (1 + extra))
+
+
+def group_flops(key):
+    return sum(2.0 * M * N * K for (M, N, K, _) in key)
+
+
+def group_bytes(key):
+    """A grouped weight-gradient launch: dY and X of every problem read once, dW read and written once (it accumulates)."""
+    return sum(4.0 * (K * M + K * N + 2 * M * N) for (M, N, K, _) in key)
 
 
 def attn_flops(name, key):
@@ -290,7 +301,7 @@ def main():
     # In-region HIP-event pairs exist only in the eager form (a replayed graph has no per-kernel host hooks) and only with --time-every:
     # they cost ~15 us of host time per launch, enough to make the host the bottleneck.  The roofline figures come from the isolated
     # single-stream steps after the timed region.
-    timed = ["gemm", "attn_fwd", "attn_bwd"]
+    timed = ["gemm", "wgrad_group", "attn_fwd", "attn_bwd"]
     if a.profile_ops:
         timed += ["layernorm_fwd", "layernorm_bwd", "colsum", "bn_fwd", "bn_bwd", "embed_fwd", "embed_bwd", "posenc_fwd", "posenc_bwd", "rowmask",
                   "add_inplace", "add_strided", "specaugment", "disc_gather", "disc_scatter", "speech_loss_fwd", "speech_loss_bwd", "text_loss_fwd",
@@ -326,7 +337,7 @@ def main():
     side = config.SIDE_STREAMS
     config.SIDE_STREAMS = False
     try:
-        with OpTimer(ops, ["gemm", "attn_fwd", "attn_bwd"]) as ot_iso:
+        with OpTimer(ops, ["gemm", "wgrad_group", "attn_fwd", "attn_bwd"]) as ot_iso:
             for i in range(a.iso_steps):
                 train.train_step(losses, model, opt, sched, batches, n_prime + a.warmup + a.steps + i, args)
             sync()
@@ -345,6 +356,10 @@ def main():
         tot = sum(v[1] for v in su[n].values())
         fl = sum((gemm_flops(k) if n == "gemm" else attn_flops(n, k)) * v[0] for k, v in su[n].items())
         by = sum(gemm_bytes(k) * v[0] for k, v in su[n].items()) if n == "gemm" else 0.0
+        if n == "gemm" and "wgrad_group" in su:      # the grouped weight-gradient launches belong to the same family (same kernel body)
+            gsu = su["wgrad_group"]
+            calls += sum(v[0] for v in gsu.values()); tot += sum(v[1] for v in gsu.values())
+            fl += sum(group_flops(k) * v[0] for k, v in gsu.items()); by += sum(group_bytes(k) * v[0] for k, v in gsu.items())
         return dict(calls=calls, ms=tot, flops=fl, bytes=by)
     fam = {n: family(iso, n) for n in ("gemm", "attn_fwd", "attn_bwd")}
     steps_iso = max(a.iso_steps, 1)
@@ -428,10 +443,10 @@ def main():
                 fl = (gemm_flops(k) if n == "gemm" else attn_flops(n, k))
                 sys.stderr.write("  %-9s %-28s calls/step %5.1f  avg %8.1f us  %7.1f TF/s\n" % (n, k, v[0] / n_timed, v[1] * 1e3 / v[0], fl * v[0] / (v[1] * 1e-3) / 1e12))
     if a.iso_detail:
-        for n in ("gemm", "attn_fwd", "attn_bwd"):
+        for n in ("gemm", "wgrad_group", "attn_fwd", "attn_bwd"):
             rows = sorted(iso[n].items(), key=lambda kv: -kv[1][1])[:16]
             for k, v in rows:
-                fl = (gemm_flops(k) if n == "gemm" else attn_flops(n, k))
+                fl = (gemm_flops(k) if n == "gemm" else group_flops(k) if n == "wgrad_group" else attn_flops(n, k))
                 sys.stderr.write("  iso %-9s %-44s calls/step %5.1f  avg %8.1f us  total %7.3f ms/step  %7.1f TF/s\n" % (
                     n, k, v[0] / steps_iso, v[1] * 1e3 / v[0], v[1] / steps_iso, fl * v[0] / (v[1] * 1e-3) / 1e12))
     print(json.dumps(out))

@@ -66,6 +66,33 @@ def test_attention_fwd_bwd(nsplit, B, Tq, Tk, causal):
     assert relerr(dKV[:, E:].reshape(B, Tk, E), v.grad) < tol
 
 
+@pytest.mark.parametrize("B,Tq,Tk,causal,p", [(2, 200, 200, True, 0.0), (3, 150, 37, False, 0.1), (2, 33, 300, False, 0.1), (2, 257, 257, True, 0.1), (1, 5, 5, False, 0.0)])
+def test_attention_backward_one_pass_equals_two_kernels(B, Tq, Tk, causal, p):
+    """The fused backward (dK, dV and dQ from one sweep; dQ summed over key blocks with fp32 atomics) against the dQ-kernel +
+    dK/dV-kernel pair on the same inputs and the same dropout stream: dK / dV bit-identical (same arithmetic), dQ to summation
+    order; ragged key lengths, rows beyond Tq untouched-then-zeroed, strided dQ view (the self-attention layout)."""
+    from unast_amd import ops, config
+    H, E = 4, 256
+    g = torch.Generator().manual_seed(B * 1000 + Tq + Tk)
+    q = torch.randn(B * Tq, E, generator=g).to(D); k = torch.randn(B * Tk, E, generator=g).to(D); v = torch.randn(B * Tk, E, generator=g).to(D)
+    lens = torch.randint(max(1, Tk // 2), Tk + 1, (B,), generator=g).to(torch.int32).to(D)
+    o = torch.empty(B * Tq, E, device=D); lse = torch.empty(B, H, Tq, device=D)
+    ops.attn_fwd(q, k, v, o, lse, lens, B, H, Tq, Tk, causal, drop_p=p, seed=7, stream_id=3)
+    dO = torch.randn(B * Tq, E, generator=g).to(D)
+    res = []
+    for fused in (False, True):
+        config.ATTN_FUSED_BWD = fused
+        ws = torch.empty(B, H, Tq, device=D)
+        dqkv = torch.full((B * Tq, 3 * E), float("nan"), device=D)          # dQ is a column slice, as in self-attention
+        dk = torch.empty(B * Tk, E, device=D); dv = torch.empty(B * Tk, E, device=D)
+        ops.attn_bwd(q, k, v, o, dO, lse, ws, dqkv[:, :E], dk, dv, lens, B, H, Tq, Tk, causal, drop_p=p, seed=7, stream_id=3)
+        assert torch.isnan(dqkv[:, E:]).all()                                # nothing written outside the dQ columns
+        res.append((dqkv[:, :E].clone(), dk, dv))
+    config.ATTN_FUSED_BWD = True
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert relerr(res[1][0], res[0][0]) < 2e-5
+
+
 def test_attention_dropout_consistency():
     """Dropout on P: forward keep-rate, determinism, and backward uses the same mask (finite-difference check on V)."""
     from unast_amd import ops

@@ -17,9 +17,13 @@ for (B, Tq, Tk, causal) in [(32, 800, 800, 0), (32, 800, 800, 1), (32, 180, 180,
     qkv = torch.randn(B * Tq, 3 * E, device=D); kv = torch.randn(B * Tk, 3 * E, device=D) if Tk != Tq else qkv
     O = torch.empty(B * Tq, E, device=D); LSE = torch.empty(B, H, Tq, device=D); lens = torch.full((B,), Tk, dtype=torch.int32, device=D)
     dO = torch.randn(B * Tq, E, device=D); ws = torch.empty(B, H, Tq, device=D); dQ = torch.empty(B * Tq, E, device=D); dKV = torch.empty(B * Tk, 2 * E, device=D)
+    from unast_amd import config
     for p in (0.0, 0.1):
+        config.ATTN_FUSED_BWD = False
+        b0 = timeit(lambda: ops.attn_bwd(qkv[:, :E], kv[:, E:2*E], kv[:, 2*E:], O, dO, LSE, ws, dQ, dKV[:, :E], dKV[:, E:], lens, B, H, Tq, Tk, causal, drop_p=p, seed=1, stream_id=1))
+        config.ATTN_FUSED_BWD = True
         f = timeit(lambda: ops.attn_fwd(qkv[:, :E], kv[:, E:2*E], kv[:, 2*E:], O, LSE, lens, B, H, Tq, Tk, causal, drop_p=p, seed=1, stream_id=1))
         b = timeit(lambda: ops.attn_bwd(qkv[:, :E], kv[:, E:2*E], kv[:, 2*E:], O, dO, LSE, ws, dQ, dKV[:, :E], dKV[:, E:], lens, B, H, Tq, Tk, causal, drop_p=p, seed=1, stream_id=1))
         pairs = Tq * (Tq + 1) / 2 if causal else Tq * Tk
         fl = 4.0 * B * H * pairs * 64
-        print((B, Tq, Tk, causal), "p=%.1f fwd %.0f us (%.0f TF)  bwd %.0f us (%.0f TF)" % (p, f, fl / f / 1e6, b, 2.5 * fl / b / 1e6), flush=True)
+        print((B, Tq, Tk, causal), "p=%.1f fwd %.0f us (%.0f TF)  bwd fused %.0f us (%.0f TF)  bwd two-kernel %.0f us" % (p, f, fl / f / 1e6, b, 2.5 * fl / b / 1e6, b0), flush=True)

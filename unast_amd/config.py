@@ -48,3 +48,6 @@ STREAM_GROUPS = dict(kv.split(":") for kv in os.environ.get("UNAST_STREAM_GROUPS
 # Weight gradients of one backward closure (an attention sub-layer's out-proj + in-proj, an FFN's two linears, ...) go out as
 # ONE grouped launch (csrc/gemm.hip gemm_group_kernel) instead of one split-K launch + one reduction each; 0 = one by one.
 WGRAD_GROUP = os.environ.get("UNAST_WGRAD_GROUP", "1") != "0"
+
+# Attention backward as ONE pass (dK, dV and dQ; csrc/attention.hip attn_dkv_kernel<*,1>) instead of a dQ kernel + a dK/dV kernel.
+ATTN_FUSED_BWD = os.environ.get("UNAST_ATTN_FUSED_BWD", "1") != "0"

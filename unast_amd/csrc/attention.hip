@@ -350,13 +350,25 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
 // dK / dV.  grid (ceil(Tk/128), H, B); wave w owns keys [128*bx + 32w, +32) and keeps dK^T, dV^T [64 x 32] in
 // accumulators while the workgroup sweeps 32-query tiles of Q and dO through LDS.
 // ------------------------------------------------------------------------------------------------------------
-template <int NSPLIT>
+// FUSE_DQ = 1: the same pass also produces dQ (5 MFMA products per (query, key) tile instead of the 7 of dQ-kernel + dK/dV-kernel,
+// which both recompute S and dP).  dQ[q,d] = scale * sum_key dS[q,key] K[key,d] contracts over the key, which sits on the LANE of
+// the dS accumulators, so dS crosses LDS once: every wave writes its [32 keys x 32 queries] block (the hi/lo bf16 words it packs
+// for the dK product anyway) into a [128 keys][2 x 32 queries] image (two query tiles side by side = double buffer), and in the
+// NEXT iteration -- behind the barrier that is there anyway -- wave w multiplies the whole 128-key column block by the
+// pre-scaled K image: dQ[32 q x 16 d (slice w)] = dS^T-fragments (transposed reads) x K-fragments (transposed reads, same
+// key permutation).  The result is the workgroup's share of dQ; key blocks are summed with fp32 atomics (each wave-instruction
+// adds 4 rows x 64 contiguous bytes), dQ is zeroed by the caller.
+template <int NSPLIT, int FUSE_DQ>
 __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
     constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
     constexpr int IMG = 32 * ALD * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PARTS * IMG];
+    constexpr int IMG128 = 128 * ALD * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PARTS * IMG + (FUSE_DQ ? 2 * PARTS * IMG128 : 0)];
     unsigned char* sQ[2] = {smem, smem + (PARTS - 1) * IMG};
     unsigned char* sD[2] = {smem + PARTS * IMG, smem + PARTS * IMG + (PARTS - 1) * IMG};
+    unsigned char* const fbase = smem + 2 * PARTS * IMG;
+    unsigned char* sKs[2] = {fbase, fbase + (PARTS - 1) * IMG128};                               // K * scale, [128 keys][64 d]
+    unsigned char* sS[2] = {fbase + PARTS * IMG128, fbase + PARTS * IMG128 + (PARTS - 1) * IMG128};   // dS, [128 keys][buf*32 + q]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
     int bx, bh;
@@ -406,14 +418,45 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
     const int qt_begin = p.causal ? (kblk / 32) : 0;
     const int qt_end = block_live ? (p.Tq + 31) / 32 : qt_begin;
     float4 rq[2], rd[2];
+    if (FUSE_DQ && qt_begin < qt_end) {          // the workgroup's 128 keys, pre-scaled, as the B operand of the dQ product
+        float4 rk8[8];
+        tile_load<128>(Kb + (size_t)kblk * p.ldk, p.ldk, min(128, p.Tk - kblk), rk8, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { rk8[i].x *= p.scale; rk8[i].y *= p.scale; rk8[i].z *= p.scale; rk8[i].w *= p.scale; }
+        tile_store<128, NSPLIT>(rk8, sKs[0], sKs[PARTS - 1], t);
+    }
     if (qt_begin < qt_end) {
         tile_load<32>(Qb + (size_t)qt_begin * 32 * p.ldq, p.ldq, min(32, p.Tq - qt_begin * 32), rq, t);
         tile_load<32>(dOb + (size_t)qt_begin * 32 * p.lddo, p.lddo, min(32, p.Tq - qt_begin * 32), rd, t);
     }
+    // dQ of query tile `qtile` from the dS image's half `buf`: wave w owns head-dim columns [16w, 16w+16)
+    auto dq_phase = [&](int qtile, int buf) {
+        f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8_t bh = tr_frag(sKs[0], 32 * kk, 16 * wave, l15, g);
+            const bf16x8_t bl = (PARTS == 2) ? tr_frag(sKs[PARTS - 1], 32 * kk, 16 * wave, l15, g) : bh;
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                const bf16x8_t ah = tr_frag(sS[0], 32 * kk, 32 * buf + 16 * qs, l15, g);
+                const bf16x8_t al = (PARTS == 2) ? tr_frag(sS[PARTS - 1], 32 * kk, 32 * buf + 16 * qs, l15, g) : ah;
+                dq[qs] = mma3<NSPLIT>(ah, al, bh, bl, dq[qs]);          // D[m = q][n = d]
+            }
+        }
+        float* dqb = p.O + (size_t)b * p.Tq * p.ldo + h * HD + 16 * wave + l15;
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = qtile * 32 + 16 * qs + 4 * g + r;
+                if (q < p.Tq) unsafeAtomicAdd(dqb + (size_t)q * p.ldo, dq[qs][r]);
+            }
+    };
     for (int qt = qt_begin; qt < qt_end; ++qt) {
         tile_store<32, NSPLIT>(rq, sQ[0], sQ[PARTS - 1], t);
         tile_store<32, NSPLIT>(rd, sD[0], sD[PARTS - 1], t);
         __syncthreads();
+        if (FUSE_DQ && qt > qt_begin) dq_phase(qt - 1, (qt - 1) & 1);
         if (qt + 1 < qt_end) {
             const int qr = (qt + 1) * 32;
             tile_load<32>(Qb + (size_t)qr * p.ldq, p.ldq, min(32, p.Tq - qr), rq, t);
@@ -482,6 +525,16 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
             pf[ks][0] = hi; if (PARTS == 2) pf[ks][PARTS - 1] = lo;
             pack_acc<NSPLIT>(dp[0][ks], dp[1][ks], hi, lo);
             sf[ks][0] = hi; if (PARTS == 2) sf[ks][PARTS - 1] = lo;
+            if (FUSE_DQ) {     // the same words, as row `key` of the dS image: queries 4g..4g+3 of both 16-row sub-tiles
+                const int row = wave * 32 + 16 * ks + l15, col = 32 * (qt & 1) + 4 * g;
+                const u32x4 hw = __builtin_bit_cast(u32x4, hi), lw = __builtin_bit_cast(u32x4, lo);
+                *reinterpret_cast<u32x2*>(sS[0] + img_off(row, col)) = (u32x2){hw[0], hw[1]};
+                *reinterpret_cast<u32x2*>(sS[0] + img_off(row, col + 16)) = (u32x2){hw[2], hw[3]};
+                if (PARTS == 2) {
+                    *reinterpret_cast<u32x2*>(sS[PARTS - 1] + img_off(row, col)) = (u32x2){lw[0], lw[1]};
+                    *reinterpret_cast<u32x2*>(sS[PARTS - 1] + img_off(row, col + 16)) = (u32x2){lw[2], lw[3]};
+                }
+            }
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -497,6 +550,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
         }
         __syncthreads();
     }
+    if (FUSE_DQ && qt_begin < qt_end) dq_phase(qt_end - 1, (qt_end - 1) & 1);
     // ---- epilogue: lane holds dK^T[d = 16dt+4g+r][key = k0+16ks+l15] ---------------------------------------
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -530,6 +584,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
         }
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
         if (h < H && (lane & 15) == 0) delta[((size_t)b * H + h) * Tq + q] = s;
+    }
+}
+
+// dst[r][0..cols) = 0 for a strided [rows x cols] view (cols % 4 == 0): dQ before the fused backward accumulates into it
+__global__ __launch_bounds__(256) void zero_cols_kernel(float* __restrict__ dst, int ld, int rows, int cols4) {
+    const size_t total = (size_t)rows * cols4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / cols4;
+        const int c = (int)(i - r * cols4);
+        *reinterpret_cast<float4*>(dst + r * ld + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -570,7 +634,7 @@ extern "C" int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* 
 extern "C" int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                               const float* dO, int lddo, const float* LSE, float* delta_ws, float* dQ, int lddq, float* dK, int lddk,
                               float* dV, int lddv, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
-                              float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream) {
+                              float drop_p, unsigned int seed, unsigned int stream_id, int fused, hipStream_t stream) {
     AttnParams p;
     int rc = fill_common(p, Q, ldq, K, ldk, V, ldv, lens_k, B, H, Tq, Tk, head_dim, causal, scale, drop_p, seed, stream_id);
     if (rc) return rc;
@@ -583,12 +647,17 @@ extern "C" int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* 
     p.dO = dO; p.lddo = lddo; p.LSE = const_cast<float*>(LSE); p.Delta = delta_ws;
     p.O = dQ; p.ldo = lddq; p.dK = dK; p.dV = dV; p.lddk = lddk; p.lddv = lddv;
     dim3 gq(xcd_grid((Tq + 127) / 128, B * H)), gk(xcd_grid((Tk + 127) / 128, B * H));
-    if (nsplit == 3) {
+    if (fused) {
+        const size_t cells = (size_t)rows * (H * HD / 4);
+        hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)((cells + 255) / 256 > 2048 ? 2048 : (cells + 255) / 256)), dim3(256), 0, stream, dQ, lddq, rows, H * HD / 4);
+        if (nsplit == 3) hipLaunchKernelGGL((attn_dkv_kernel<3, 1>), gk, dim3(256), 0, stream, p);
+        else             hipLaunchKernelGGL((attn_dkv_kernel<1, 1>), gk, dim3(256), 0, stream, p);
+    } else if (nsplit == 3) {
         hipLaunchKernelGGL((attn_q_kernel<3, 1>), gq, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL((attn_dkv_kernel<3>), gk, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_dkv_kernel<3, 0>), gk, dim3(256), 0, stream, p);
     } else {
         hipLaunchKernelGGL((attn_q_kernel<1, 1>), gq, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL((attn_dkv_kernel<1>), gk, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_dkv_kernel<1, 0>), gk, dim3(256), 0, stream, p);
     }
     return unast_check_launch("unast_attn_bwd");
 }

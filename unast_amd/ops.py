@@ -236,9 +236,11 @@ def _launch_group(chunk, offload):
     if ws_n <= 0:
         raise RuntimeError("unast_wgrad_group_ws_floats failed")
 
+    shapes = tuple((int(a.M), int(a.N), int(a.K), int(a.rowsum_a is not None)) for a in arr)
+
     def launch():
-        ws = torch.empty(ws_n, dtype=torch.float32, device=chunk[0][0].device)
-        check(lib().unast_wgrad_group(config.NSPLIT, n, ptr, _p(ws), ws_n, WGRAD_GROUP_TARGET, _stream()), "unast_wgrad_group")
+        import sys
+        sys.modules[__name__].wgrad_group(shapes, n, ptr, ws_n, chunk[0][0].device)       # looked up at call time: bench.py wraps it with HIP events
     if offload:
         w = WGRAD_SIDE()
         w.wait_stream(torch.cuda.current_stream())
@@ -248,6 +250,12 @@ def _launch_group(chunk, offload):
             launch()
     else:
         launch()
+
+
+def wgrad_group(shapes, n, items_ptr, ws_n, device):
+    """The grouped launch itself (GEMM + reduction on the current stream); `shapes` = ((out, in, tokens, has_bias), ...) for bookkeeping."""
+    ws = torch.empty(ws_n, dtype=torch.float32, device=device)
+    check(lib().unast_wgrad_group(config.NSPLIT, n, items_ptr, _p(ws), ws_n, WGRAD_GROUP_TARGET, _stream()), "unast_wgrad_group")
 
 
 def linear_wgrad(dy2d, x2d, dW, db=None):
@@ -298,7 +306,7 @@ def attn_bwd(Q, K, V, O, dO, LSE, delta_ws, dQ, dK, dV, lens_k, B, H, Tq, Tk, ca
     check(lib().unast_attn_bwd(nsplit or config.NSPLIT, _p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0),
                                _p(dO), dO.stride(0), _p(LSE), _p(delta_ws), _p(dQ), dQ.stride(0), _p(dK), dK.stride(0), _p(dV),
                                dV.stride(0), _p(lens_k), B, H, Tq, Tk, 64, int(causal), 0.125, drop_p, seed & 0xFFFFFFFF, stream_id,
-                               _stream()), "unast_attn_bwd")
+                               int(config.ATTN_FUSED_BWD), _stream()), "unast_attn_bwd")
 
 
 # ---- normalisation -----------------------------------------------------------------------------------------
