@@ -126,6 +126,10 @@ def join_streams():
         _Streams.used.clear()
 
 
+import os as _os
+_FORCE_VIA_ORIGIN = _os.environ.get("UNAST_VIA_ORIGIN", "0") == "1"      # experiment: the capture-time hand-off discipline in eager mode
+
+
 class _ViaOrigin(torch.autograd.Function):
     """Identity placed -- on the CALLER's stream -- on an edge between two side streams while a HIP graph is being captured.
     ROCm 7.2's hipStreamEndCapture crashes when a side stream waits on an event of another side stream that has itself waited
@@ -155,7 +159,7 @@ def on_stream(name):
             s = _side(name)
             if cur == s:
                 return fn(*args, **kw)
-            via_origin = torch.cuda.is_current_stream_capturing()
+            via_origin = torch.cuda.is_current_stream_capturing() or _FORCE_VIA_ORIGIN
             waited = set()
             inputs = set()
             cross = set()

@@ -25,6 +25,10 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_F32 = torch.float32
+_LN_WS = {}
+
+
 def _f32(t, name):
     if t is None:
         return
@@ -54,8 +58,9 @@ def _presplit_ptr(ptr):
 
 def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bias=None, R=None, ldr=0, G=None,
          ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False, rowsum_a=None, kb_valid=0, tile_wn=0):
-    for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (R, "R"), (G, "G")):
-        _f32(t, n)
+    if A.dtype is not _F32 or B.dtype is not _F32 or C.dtype is not _F32 or not C.is_cuda:       # (epilogue operands are produced by this package)
+        for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (R, "R"), (G, "G")):
+            _f32(t, n)
     ws, ws_n = None, 0
     if splitk > 1 and not atomic:
         ws_n = splitk * M * ((N + 3) // 4 * 4)
@@ -231,7 +236,7 @@ def _launch_group(chunk, offload):
         a.rowsum_a = db.data_ptr() if db is not None else None
         a.M, a.N, a.K = dy2d.shape[1], x2d.shape[1], dy2d.shape[0]
         operands += [dy2d, x2d]
-    ptr = _ct.cast(arr, _ct.c_void_p)
+    ptr = _ct.addressof(arr)              # `arr` stays referenced by the closure below until the launch has been issued
     ws_n = lib().unast_wgrad_group_ws_floats(n, ptr, WGRAD_GROUP_TARGET)
     if ws_n <= 0:
         raise RuntimeError("unast_wgrad_group_ws_floats failed")
@@ -319,7 +324,9 @@ def layernorm_bwd(dy, z, gamma, mean, rstd, dz, dz_drop=None, dgamma=None, dbeta
     rows, C = z.shape
     ws, ws_n = None, 0
     if dgamma is not None:
-        ws_n = lib().unast_layernorm_bwd_ws_floats(rows, C)
+        ws_n = _LN_WS.get((rows, C))
+        if ws_n is None:
+            ws_n = _LN_WS[(rows, C)] = lib().unast_layernorm_bwd_ws_floats(rows, C)
         ws = torch.empty(ws_n, dtype=torch.float32, device=z.device)
     check(lib().unast_layernorm_bwd(_p(dy), _p(z), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dz_drop), _p(dgamma), _p(dbeta), _p(ws), ws_n,
                                     rows, C, drop_p, seed & 0xFFFFFFFF, stream_id, 0 if dgamma is not None else 1, _stream()), "unast_layernorm_bwd")
@@ -600,7 +607,7 @@ def set_step_state(epoch, hyper_by_slot):
         for j, v in enumerate(vals):
             words[4 + 3 * slot + j] = struct.unpack("<I", struct.pack("<f", float(v)))[0]
         n = max(n, 4 + 3 * slot + 3)
-    check(lib().unast_set_words(_p(step_state()), ctypes.cast(words, ctypes.c_void_p), n, _stream()), "unast_set_words")
+    check(lib().unast_set_words(_p(step_state()), ctypes.addressof(words), n, _stream()), "unast_set_words")
 
 
 def hyper_slot(i):
