@@ -48,29 +48,9 @@ def parse_header(path=HEADER_PATH):
     return protos
 
 
-_fast = None
-
-
 def lib():
-    """The C ABI as a namespace of callables (`lib().unast_gemm(...)`): the generated CPython bindings of the header
-    (unast_amd/_fastcall, csrc/gen_fastcall.py) when they are built -- same positional arguments, ~10x less marshalling time
-    per call than ctypes -- else the ctypes binding below.  UNAST_HIP_LIB (kernel experiments) and UNAST_BINDING=ctypes force
-    ctypes.  Fails loudly when the HIP library is missing (there is no CPU fallback)."""
-    global _fast
-    if _fast is not None:
-        return _fast
-    if not os.environ.get("UNAST_HIP_LIB") and os.environ.get("UNAST_BINDING", "fast") != "ctypes":
-        ctypes_lib()                                   # loads libunast_hip.so (and checks every declared symbol) first
-        try:
-            from . import _fastcall
-            missing = [n for n in parse_header() if not hasattr(_fastcall, n)]
-            if not missing:
-                _fast = _fastcall
-                return _fast
-        except ImportError:
-            pass
-    _fast = ctypes_lib()
-    return _fast
+    """Loads the HIP library; fails loudly when it is missing (there is no CPU fallback)."""
+    return ctypes_lib()
 
 
 def ctypes_lib():
