@@ -236,6 +236,8 @@ def main():
 
     from unast_amd import config, ops, train, utils
     from unast_amd.configs import make_args
+    if os.environ.get("UNAST_AUTOGRAD_ST", "0") == "1":        # experiment: backward closures on the calling thread
+        torch.autograd.set_multithreading_enabled(False)
     config.set_precision(a.precision)
     B, Tt, Tm, L, use_disc = WORKLOADS[a.workload]
     args = make_args(num_layers=L, ae_steps=1, sp_steps=1, d_steps=1, cm_steps=a.cm_steps, use_discriminator=use_disc)

@@ -244,6 +244,12 @@ int unast_adamw(float* p, const float* g, float* m, float* v, int64_t n, const d
                 float beta1, float beta2, float eps, float weight_decay, int step, float* split_out, int decoupled,
                 const float* dev_hyper, hipStream_t stream);
 int unast_split_f32(const float* src, float* dst, int64_t n, hipStream_t stream);
+/* W^T of every 2-D weight of a parameter region once more in the pre-split operand format (dst[k][n], 4 consecutive n per 16-byte
+ * chunk; destination rows padded to a multiple of 4 with zeros), refreshed after each optimizer step: the input-gradient GEMMs
+ * (autograd of nn.Linear, src/module.py:18-39) then read it as a K-contiguous B operand.  tiles_dev: ntiles x 6 int32 in device
+ * memory {src offset, dst offset, rows, cols, row0, col0} per 64 x 64 tile (float offsets from the bases; cols % 4 == 0, source
+ * offsets multiples of 4). */
+int unast_transpose_split(const float* src_base, float* dst_base, const int* tiles_dev, int ntiles, hipStream_t stream);
 /* Writes n <= 16 32-bit words (read from HOST memory at call time, passed by value in the kernel arguments) to device memory:
  * refreshes the block a captured step reads (RNG epoch of unast_set_rng_epoch, dev_hyper triples of unast_adamw) once per
  * replay; stands where the reference's Python passes lr / step to torch.optim (src/train.py:361, 654-655). */

@@ -174,6 +174,7 @@ st.touched = {"gen"}
 br = ddp.bucket_ranges(st)
 assert br == {"text_enc": (0, 256), "text_dec": (256, 512), "speech_enc": (512, 704), "speech_dec": (704, 960)}, br
 exp = torch.arange(1024, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+tot = torch.arange(1024, dtype=torch.float32) * sum(range(1, world + 1))          # summed, not yet scaled by 1/world (finish() scales)
 own = torch.arange(1024, dtype=torch.float32) * (rank + 1)
 # --- generator phase: armed in the last sub-step; the speech encoder is used by two calls (both must finish first) ---
 ddp.segment_backward("text_dec", st)                     # not armed yet (an earlier sub-step): nothing may travel
@@ -182,7 +183,7 @@ ddp.arm()
 for b in ("text_enc", "speech_enc", "speech_enc", "speech_dec", "text_dec"):
     ddp.segment_forward(b)
 ddp.segment_backward("text_dec", st)
-assert [l[0] for l in ddp._State.log] == ["text_dec"] and torch.allclose(st.grad[256:512], exp[256:512])
+assert [l[0] for l in ddp._State.log] == ["text_dec"] and torch.allclose(st.grad[256:512], tot[256:512])
 assert torch.equal(st.grad[:256], own[:256]) and torch.equal(st.grad[512:], own[512:])       # everything else still local
 ddp.segment_backward("speech_dec", st)
 ddp.segment_backward("speech_enc", st)                   # first of two users: not final yet

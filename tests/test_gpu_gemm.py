@@ -256,3 +256,54 @@ def test_grouped_weight_gradients_general_shapes():
         assert relerr(dW, rW) < 3e-5 and relerr(db, rb) < 1e-5
     # too small a workspace is refused, not overrun
     assert lib().unast_wgrad_group(3, len(probs), ptr, ws.data_ptr(), n - 1, 0, torch.cuda.current_stream().cuda_stream) != 0
+
+
+def test_dgrad_through_transposed_presplit_weights():
+    """Input gradients of stored weights read W^T from the transposed pre-split copy (engine.FlatStore.dgrad_T): same results as
+    the untransposed form for whole matrices, row slices (cross-attention's q / kv halves of in_proj), padded heads (81 -> 84,
+    46 -> 48 rows) and the LSTM's combined [fwd | reverse] input weights -- before and after an optimizer step refreshed it."""
+    from unast_amd import ops, config, train, utils
+    from unast_amd.configs import make_args
+    train.DEVICE = dev()
+    utils.set_seed(3)
+    args = make_args(num_layers=1, ae_steps=1, sp_steps=1, d_steps=1, cm_steps=0)
+    _, _, model, opt, _ = train.initialize_model(args)
+    st = model._store()
+    st.sync_split()
+    g = torch.Generator().manual_seed(5)
+    P = st.phys
+    inp = P["speech_m.decoder.transformer_decoder.layers.0.multihead_attn.in_proj_weight"]
+    cases = [("whole", P["text_m.encoder.transformer_encoder.layers.0.linear1.weight"]), ("q-slice", inp[:256]), ("kv-slice", inp[256:]),
+             ("head81", st.span("speech_m.postnet.linear_project.weight", "speech_m.postnet.stop_linear.weight", (81, 256))),
+             ("logits46", P["text_m.postnet.fc1.weight"]),
+             ("lstm", st.span("discriminator.rnn.rnn.weight_ih_l0", "discriminator.rnn.rnn.weight_ih_l0_reverse", (512, 256))),
+             ("fc2", P["discriminator.fc2.weight"])]
+
+    def check_all():
+        for name, W in cases:
+            N, K = W.shape
+            assert st.dgrad_T(W) is not None, name
+            Np = (N + 3) // 4 * 4
+            M = 384
+            dyb = torch.zeros(M, Np, device=dev()); dyb[:, :N] = torch.randn(M, N, generator=g).to(dev())
+            R = torch.randn(M, K, generator=g).to(dev()); G = torch.randn(M, K, generator=g).to(dev())
+            outs = []
+            for flag in (True, False):
+                config.DGRAD_TRANSPOSED = flag
+                dx = torch.empty(M, K, device=dev())
+                ops.linear_dgrad(dyb[:, :N], W, dx, R=R, G=G, gate_scale=1.25)
+                outs.append(dx)
+            config.DGRAD_TRANSPOSED = True
+            ref = (dyb[:, :N].double().cpu() @ W.double().cpu()) * (G.cpu() > 0).double() * 1.25 + R.double().cpu()
+            assert relerr(outs[0], ref) < 3e-5, name
+            assert relerr(outs[0], outs[1].double().cpu()) < 1e-6, name
+    check_all()
+    # one optimizer step over both regions moves the weights: the transposed copies follow
+    st.grad.normal_(generator=None)
+    st.touched = {"gen", "disc"}
+    before = st.flat.clone()
+    opt.param_groups[0]["lr"] = 1e-2
+    opt.step(max_norm=1.0)
+    opt.zero_grad()
+    assert not torch.equal(before, st.flat)
+    check_all()

@@ -4,8 +4,8 @@
 # usage (GPU box, repo root): bash tools/pmc_hbm_traffic.sh <out-json-basename>
 name=${1:-pmc_hbm_traffic}; root=$PWD; out=$root/gpurun_out/$name
 mkdir -p $out; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/fetch.log 2>&1 || echo "fetch pass failed"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/write.log 2>&1 || echo "write pass failed"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --launch eager > $out/fetch.log 2>&1 || echo "fetch pass failed"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --launch eager > $out/write.log 2>&1 || echo "write pass failed"
 cd $root
 python3 - <<PY
 import csv, glob, json, collections, re

@@ -567,8 +567,9 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
 }
 
 // Delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]; one wave per (b,q) row of H*64 = 256 columns (H == 4) or generic H.
+// zero_dq (may be NULL): the same rows of dQ are cleared on the way (the one-pass backward accumulates into dQ with atomics).
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dO, int lddo, const float* __restrict__ O, int ldo,
-                                                         float* __restrict__ delta, int rows, int Tq, int H) {
+                                                         float* __restrict__ delta, int rows, int Tq, int H, float* __restrict__ zero_dq, int lddq) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -581,19 +582,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
             float4 a = *reinterpret_cast<const float4*>(dO + (size_t)row * lddo + c);
             float4 o = *reinterpret_cast<const float4*>(O + (size_t)row * ldo + c);
             s = (a.x * o.x + a.y * o.y) + (a.z * o.z + a.w * o.w);
+            if (zero_dq) *reinterpret_cast<float4*>(zero_dq + (size_t)row * lddq + c) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
         if (h < H && (lane & 15) == 0) delta[((size_t)b * H + h) * Tq + q] = s;
-    }
-}
-
-// dst[r][0..cols) = 0 for a strided [rows x cols] view (cols % 4 == 0): dQ before the fused backward accumulates into it
-__global__ __launch_bounds__(256) void zero_cols_kernel(float* __restrict__ dst, int ld, int rows, int cols4) {
-    const size_t total = (size_t)rows * cols4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t r = i / cols4;
-        const int c = (int)(i - r * cols4);
-        *reinterpret_cast<float4*>(dst + r * ld + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -643,13 +635,11 @@ extern "C" int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* 
                   "unast_attn_bwd: operands must be 16-byte aligned with ld%%4==0");
     UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_attn_bwd: nsplit must be 1 or 3");
     const int rows = B * Tq;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, dO, lddo, O, ldo, delta_ws, rows, Tq, H);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, dO, lddo, O, ldo, delta_ws, rows, Tq, H, fused ? dQ : nullptr, lddq);
     p.dO = dO; p.lddo = lddo; p.LSE = const_cast<float*>(LSE); p.Delta = delta_ws;
     p.O = dQ; p.ldo = lddq; p.dK = dK; p.dV = dV; p.lddk = lddk; p.lddv = lddv;
     dim3 gq(xcd_grid((Tq + 127) / 128, B * H)), gk(xcd_grid((Tk + 127) / 128, B * H));
     if (fused) {
-        const size_t cells = (size_t)rows * (H * HD / 4);
-        hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)((cells + 255) / 256 > 2048 ? 2048 : (cells + 255) / 256)), dim3(256), 0, stream, dQ, lddq, rows, H * HD / 4);
         if (nsplit == 3) hipLaunchKernelGGL((attn_dkv_kernel<3, 1>), gk, dim3(256), 0, stream, p);
         else             hipLaunchKernelGGL((attn_dkv_kernel<1, 1>), gk, dim3(256), 0, stream, p);
     } else if (nsplit == 3) {

@@ -113,6 +113,43 @@ extern "C" int unast_set_words(unsigned int* dst, const unsigned int* host_words
     return unast_check_launch("unast_set_words");
 }
 
+// Transposed pre-split copies of the 2-D weights: dst[k][n] (chunks of 4 consecutive n: [hi x4 | lo x4]) = src[n][k], for the input-
+// gradient GEMMs dX = dY W, which then read W^T K-contiguously exactly like the forward GEMMs read W (one ds_read_b128 per
+// fragment instead of two transposed reads, and no re-splitting).  One launch covers every matrix of a region: `tiles` holds one
+// descriptor per 64 x 64 tile {src offset, dst offset, rows N, cols K, row0, col0} (offsets in floats from the two bases);
+// columns n >= N of a padded destination row are written as zeros.
+__global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
+                                                              const int* __restrict__ tiles) {
+    __shared__ float tile[64][65];
+    const int* d = tiles + (size_t)blockIdx.x * 6;
+    const int N = d[2], K = d[3], r0 = d[4], c0 = d[5];
+    const float* src = src_base + d[0];
+    float* dst = dst_base + d[1];
+    const int ldT = (N + 3) & ~3;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + 256 * i, r = idx >> 4, c4 = (idx & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < N && c0 + c4 < K) v = *reinterpret_cast<const float4*>(src + (size_t)(r0 + r) * K + c0 + c4);      // K % 4 == 0
+        tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + 256 * i, k = idx >> 4, n4 = (idx & 15) * 4;
+        if (c0 + k < K && r0 + n4 < ldT)
+            *reinterpret_cast<uint4*>(dst + (size_t)(c0 + k) * ldT + r0 + n4) = split_chunk(make_float4(tile[n4][k], tile[n4 + 1][k], tile[n4 + 2][k], tile[n4 + 3][k]));
+    }
+}
+
+extern "C" int unast_transpose_split(const float* src_base, float* dst_base, const int* tiles_dev, int ntiles, hipStream_t stream) {
+    UNAST_REQUIRE(src_base && dst_base && tiles_dev && ntiles > 0, "unast_transpose_split: bad arguments");
+    UNAST_REQUIRE(((((uintptr_t)src_base) | ((uintptr_t)dst_base)) & 15) == 0, "unast_transpose_split: bases must be 16-byte aligned");
+    hipLaunchKernelGGL(transpose_split_kernel, dim3(ntiles), dim3(256), 0, stream, src_base, dst_base, tiles_dev);
+    return unast_check_launch("unast_transpose_split");
+}
+
 extern "C" int unast_split_f32(const float* src, float* dst, int64_t n, hipStream_t stream) {
     UNAST_REQUIRE(src && dst && n > 0 && (n & 3) == 0, "unast_split_f32: need n %% 4 == 0 (n=%lld)", (long long)n);
     UNAST_REQUIRE(((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "unast_split_f32: buffers must be 16-byte aligned");

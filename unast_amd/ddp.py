@@ -9,10 +9,10 @@ is cut into four contiguous BUCKETS in the order the backward pass finishes them
 Gradients accumulate over the generator sub-steps of one outer step (ae / cm / sp, /root/reference/src/train.py:608-628), so a
 bucket is final only in the LAST of them.  train_step arms the exchange before that sub-step; when the backward of a public
 model call (`decode_sequence`, `encode`) has been enqueued and it was the last user of its bucket, the bucket's all-reduce is
-issued on a communication stream that waits for the producing streams (the side stream of that call and the weight-gradient
-companion streams) -- so the two decoder buckets (55 % of the bytes) travel while the backward continues through the frozen
-LSTM discriminator and the encoders.  The optimizer step waits for the communication stream, reduces whatever was not
-pre-issued (the encoder buckets' tail, the discriminator phase's 0.28 M floats, any call pattern the hooks did not see), and
+issued asynchronously behind the streams that produced it (the side stream of that call and the weight-gradient companion
+streams; RCCL runs it on the process group's own stream) -- so the two decoder buckets (55 % of the bytes) travel while the
+backward continues through the frozen LSTM discriminator and the encoders.  The optimizer step waits for those collectives,
+reduces whatever was not pre-issued (the encoder buckets' tail, the discriminator phase's 0.28 M floats, any call pattern the hooks did not see), and
 only then computes the global norm: the reference's order (generator update before the D-phase forward,
 /root/reference/src/train.py:628-637) is kept.
 
@@ -42,8 +42,8 @@ class _State:
     armed = False
     fwd_count = {}          # bucket -> forward segments recorded (with a tape) since arm()
     bwd_count = {}
-    issued = []             # [(a, b)] ranges whose all-reduce is already on the communication stream (this optimizer phase)
-    comm = {}               # device index -> torch.cuda.Stream
+    issued = []             # [(a, b)] ranges whose all-reduce has been issued (this optimizer phase)
+    pending = []            # work handles of the pre-issued collectives
     log = []                # (bucket or "rest", a, b) in issue order -- read by tests
     scale_fn = None         # test hook: CPU tensors have no HIP scale kernel
 
@@ -85,12 +85,18 @@ def bucket_ranges(store):
     return out
 
 
-def _comm_stream(device):
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    s = _State.comm.get(idx)
-    if s is None:
-        s = _State.comm[idx] = torch.cuda.Stream(device=device)
-    return s
+def _issue_stream():
+    """The stream a pre-issued bucket's all-reduce is enqueued behind: the weight-gradient companion of the current side stream
+    when there is one (after it has joined the current stream), else the current stream itself.  No stream of its own: with
+    the four of the train step's schedule plus RCCL's internal one the hardware queues are already shared, and a fifth user
+    stream cost 2.6 ms/step on the one-GPU box (36.1 vs 33.5 ms, forced single-rank nccl)."""
+    from . import engine
+    cur = torch.cuda.current_stream()
+    w = engine._wgrad_stream_of_current() if engine._Streams.enabled or engine._Streams.used else None
+    if w is not None and w != cur:
+        w.wait_stream(cur)
+        return w
+    return cur
 
 
 def arm():
@@ -129,23 +135,19 @@ def _issue(store, label, rng, overlap):
     dist = _dist()
     a, b = rng
     buf = store.grad[a:b]
-    ws = dist.get_world_size()
-    scale = _State.scale_fn or ops.scale_inplace
     if buf.is_cuda and overlap:
         from . import engine
-        comm = _comm_stream(buf.device)
-        cur = torch.cuda.current_stream()
-        comm.wait_stream(cur)
+        s = _issue_stream()
         for name in list(engine._Streams.used):          # weight / LayerNorm-parameter gradients live on the companion streams
-            s = engine._side(name)
-            if s != cur:
-                comm.wait_stream(s)
-        with torch.cuda.stream(comm):
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)    # RCCL: enqueued behind `comm`, which then waits for its completion
-            scale(buf, 1.0 / ws)
+            if name.endswith("_w"):
+                c = engine._side(name)
+                if c != s:
+                    s.wait_stream(c)
+        with torch.cuda.stream(s):
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)   # RCCL: runs behind `s` on the group's own stream
+        _State.pending.append(work)
     else:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        scale(buf, 1.0 / ws)
     _State.issued.append(rng)
     _State.log.append((label, a, b))
 
@@ -168,20 +170,23 @@ def _subtract(rng, done):
 
 
 def finish(store, ranges):
-    """Optimizer-step side: the current stream waits for the pre-issued buckets and reduces the rest of the active gradient
-    ranges.  Returns the number of collectives issued here (0 when not distributed)."""
+    """Optimizer-step side: the current stream waits for the pre-issued buckets, reduces the rest of the active gradient
+    ranges and scales everything by 1/world.  Returns the number of collectives issued here (0 when not distributed)."""
     disarm()
     if not active():
-        _State.issued = []
+        _State.issued, _State.pending = [], []
         return 0
+    dist = _dist()
     n = 0
     for rng in ranges:
         for part in _subtract(rng, _State.issued):
             _issue(store, "rest", part, overlap=False)
             n += 1
-    if store.grad.is_cuda:
-        comm = _State.comm.get(store.grad.device.index if store.grad.device.index is not None else torch.cuda.current_device())
-        if comm is not None:
-            torch.cuda.current_stream().wait_stream(comm)
-    _State.issued = []
+    for work in _State.pending:
+        work.wait()                                        # the current stream waits for that collective (no host block with RCCL)
+    scale = _State.scale_fn or ops.scale_inplace
+    ws = dist.get_world_size()
+    for a, b in ranges:
+        scale(store.grad[a:b], 1.0 / ws)
+    _State.issued, _State.pending = [], []
     return n

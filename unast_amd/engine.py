@@ -382,7 +382,8 @@ class FlatStore:
         # the weights once more in the GEMM's pre-split operand format (same byte offsets; refreshed by the AdamW kernel)
         self.flat_split = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self._split_ver = None
-        ops.register_weight_span(self.flat.data_ptr(), self.total * 4, self.flat_split.data_ptr())
+        self._build_transposed()
+        ops.register_weight_span(self.flat.data_ptr(), self.total * 4, self.flat_split.data_ptr(), self.dgrad_T)
         self.dummy = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)   # forces autograd to call our backward
         self.touched = set()           # regions that received gradients since the last zero_grad
         self.grads_exposed = False
@@ -393,6 +394,73 @@ class FlatStore:
         except Exception:
             pass
 
+    # transposed pre-split weights (B operand of the input-gradient GEMMs) -------------------------------------------
+    def _build_transposed(self):
+        """Every 2-D weight W [rows, K] (and the combined operands that are used as one matrix) gets a slot for W^T in the
+        pre-split format, [K][ceil4(rows)]; `refresh_T` fills the slots of a region with one launch (csrc/optim.hip
+        transpose_split_kernel) after every optimizer step and whenever sync_split() re-splits the weights."""
+        from . import config
+        self._tmats, self._tcache, self.flat_T, self._ttiles = [], {}, None, {}
+        if not config.DGRAD_TRANSPOSED:
+            return
+        cands = []
+        for n, p in self.params.items():
+            if p.dim() == 2 and not n.endswith(".conv.weight"):
+                cands.append((self.offsets[n], p.shape[0], p.shape[1], _region_of(n)))
+        P = self.params
+        if "speech_m.postnet.linear_project.weight" in P:                      # [linear_project | stop_linear] -> one [81, 256] head
+            a, b = P["speech_m.postnet.linear_project.weight"], P["speech_m.postnet.stop_linear.weight"]
+            cands.append((self.offsets["speech_m.postnet.linear_project.weight"], a.shape[0] + b.shape[0], a.shape[1], "gen"))
+        for n, p in P.items():                                                    # LSTM [weight_ih | weight_ih_reverse] -> [2 * 4H, Din]
+            if n.startswith("discriminator.rnn.rnn.weight_ih_l") and not n.endswith("_reverse") and (n + "_reverse") in P:
+                cands.append((self.offsets[n], 2 * p.shape[0], p.shape[1], "disc"))
+        t_off = 0
+        for off, rows, K, region in cands:
+            if K % 4 or off % 4:
+                continue
+            ldT = (rows + 3) // 4 * 4
+            self._tmats.append((off, rows, K, t_off, ldT, region))
+            t_off += (K * ldT + ALIGN - 1) // ALIGN * ALIGN
+        self.flat_T = torch.zeros(max(t_off, 4), dtype=torch.float32, device=self.device)
+        for region in ("gen", "disc", "disc_unused"):
+            tiles = []
+            for off, rows, K, to, ldT, rg in self._tmats:
+                if rg != region:
+                    continue
+                for r0 in range(0, ldT, 64):
+                    for c0 in range(0, K, 64):
+                        tiles += [off, to, rows, K, r0, c0]
+            if tiles:
+                self._ttiles[region] = (torch.tensor(tiles, dtype=torch.int32, device=self.device), len(tiles) // 6)
+
+    def refresh_T(self, regions=None):
+        for region, (tiles, n) in self._ttiles.items():
+            if regions is None or region in regions:
+                ops.transpose_split(self.flat, self.flat_T, tiles, n)
+
+    def dgrad_T(self, W):
+        """(W^T view pointer, its row stride) for a weight view W [N, K] inside the flat store, or None."""
+        if self.flat_T is None or W.dim() != 2 or W.stride(1) != 1:
+            return None
+        key = (W.data_ptr(), W.shape[0], W.shape[1])
+        hit = self._tcache.get(key, 0)
+        if hit != 0:
+            return hit
+        res = None
+        pos = (W.data_ptr() - self.flat.data_ptr()) // 4
+        N, K = W.shape
+        if W.stride(0) == K:
+            for off, rows, Km, to, ldT, rg in self._tmats:
+                if Km == K and off <= pos < off + rows * K and (pos - off) % K == 0:
+                    row0 = (pos - off) // K
+                    if row0 % 4 == 0 and row0 + N <= rows and (row0 + N == rows or N % 4 == 0):
+                        # the slice's last chunk may only run into the zero padding, never into a neighbour's rows
+                        res = (self.flat_T.data_ptr() + 4 * (to + row0), ldT)
+                        if row0 + N == rows:
+                            break
+        self._tcache[key] = res
+        return res
+
     def sync_split(self):
         """Re-split the weights if any parameter was written through torch since the last look (load_state_dict, manual
         edits: they bump the parameter's version counter; the AdamW kernel updates both copies itself)."""
@@ -401,6 +469,7 @@ class FlatStore:
             ver += p._version
         if ver != self._split_ver:
             ops.split_f32(self.flat, self.flat_split)
+            self.refresh_T()
             self._split_ver = ver
 
     # combined operands ---------------------------------------------------------------------------------------

@@ -40,9 +40,9 @@ def _f32(t, name):
 _WEIGHT_SPANS = []
 
 
-def register_weight_span(base_ptr, nbytes, split_ptr):
+def register_weight_span(base_ptr, nbytes, split_ptr, transposed_lookup=None):
     _WEIGHT_SPANS[:] = [s for s in _WEIGHT_SPANS if s[0] != base_ptr]
-    _WEIGHT_SPANS.append((base_ptr, nbytes, split_ptr))
+    _WEIGHT_SPANS.append((base_ptr, nbytes, split_ptr, transposed_lookup))
 
 
 def unregister_weight_span(base_ptr):
@@ -50,14 +50,25 @@ def unregister_weight_span(base_ptr):
 
 
 def _presplit_ptr(ptr):
-    for base, nbytes, split in _WEIGHT_SPANS:
+    for base, nbytes, split, _ in _WEIGHT_SPANS:
         if base <= ptr < base + nbytes:
             return split + (ptr - base)
     return 0
 
 
+def _transposed_weight(W):
+    """(pointer, row stride) of W^T in the pre-split format if W is a stored weight that has one (engine.FlatStore.dgrad_T)."""
+    ptr = W.data_ptr()
+    for base, nbytes, split, lookup in _WEIGHT_SPANS:
+        if lookup is not None and base <= ptr < base + nbytes:
+            return lookup(W)
+    return None
+
+
 def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bias=None, R=None, ldr=0, G=None,
-         ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False, rowsum_a=None, kb_valid=0, tile_wn=0):
+         ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False, rowsum_a=None, kb_valid=0, tile_wn=0,
+         b_ptr=None):
+    """b_ptr: B given as a raw device pointer to a PRE-SPLIT operand (a transposed weight copy); `B` is then only a shape/dtype witness."""
     if A.dtype is not _F32 or B.dtype is not _F32 or C.dtype is not _F32 or not C.is_cuda:       # (epilogue operands are produced by this package)
         for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (R, "R"), (G, "G")):
             _f32(t, n)
@@ -66,7 +77,9 @@ def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bia
         ws_n = splitk * M * ((N + 3) // 4 * 4)
         ws = torch.empty(ws_n, dtype=torch.float32, device=C.device)          # split-K partial slabs (caching allocator)
     bp, presplit = _p(B), 0
-    if _WEIGHT_SPANS and config.PRESPLIT_WEIGHTS and a_mode != OP_RC:      # forward / dgrad forms: B may be a stored weight
+    if b_ptr is not None:
+        bp, presplit = b_ptr, 1
+    elif _WEIGHT_SPANS and config.PRESPLIT_WEIGHTS and a_mode != OP_RC:      # forward / dgrad forms: B may be a stored weight
         sp = _presplit_ptr(bp)
         if sp:
             bp, presplit = sp, 1
@@ -110,6 +123,12 @@ def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0):
     Np = (N + 3) // 4 * 4          # dy2d is a view of a zero-padded buffer when N % 4 != 0 (logits 46->48, head 81->84, fc2 1->4)
     if Np != N and dy2d.stride(0) < Np:
         raise ValueError("linear_dgrad: dy must live in a zero-padded buffer with row stride >= %d" % Np)
+    wt = _transposed_weight(W) if config.DGRAD_TRANSPOSED else None
+    if wt is not None:             # dX = dY (W^T)^T with W^T stored pre-split and K-contiguous: the forward GEMM's operand form
+        gemm(OP_KC, OP_KC, dy2d, dy2d.stride(0), W, wt[1], dx, dx.stride(0), M, K, Np, R=R,
+             ldr=(R.stride(0) if R is not None else 0), G=G, ldg=(G.stride(0) if G is not None else 0),
+             gate_scale=gate_scale, beta=beta, b_ptr=wt[0])
+        return dx
     gemm(OP_KC, OP_RC, dy2d, dy2d.stride(0), W, W.stride(0), dx, dx.stride(0), M, K, Np, R=R,
          ldr=(R.stride(0) if R is not None else 0), G=G, ldg=(G.stride(0) if G is not None else 0),
          gate_scale=gate_scale, beta=beta, kb_valid=N)
@@ -563,6 +582,10 @@ def adam_hyper(lr, beta1, beta2, step):
     import math
     b1, b2 = ctypes.c_float(beta1).value, ctypes.c_float(beta2).value
     return [float(lr), 1.0 - b1 ** int(step), math.sqrt(1.0 - b2 ** int(step))]
+
+
+def transpose_split(src_flat, dst_flat, tiles_i32, ntiles):
+    check(lib().unast_transpose_split(_p(src_flat), _p(dst_flat), _p(tiles_i32), ntiles, _stream()), "unast_transpose_split")
 
 
 def split_f32(src, dst):
