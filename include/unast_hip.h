@@ -255,6 +255,16 @@ int unast_transpose_split(const float* src_base, float* dst_base, const int* til
  * replay; stands where the reference's Python passes lr / step to torch.optim (src/train.py:361, 654-655). */
 int unast_set_words(unsigned int* dst, const unsigned int* host_words, int n, hipStream_t stream);
 
+/* Stream replay of a captured HIP graph (csrc/graph_exec.cpp): the nodes of `graph` (a hipGraph_t, e.g. torch.cuda.CUDAGraph's
+ * raw handle of the captured train step -- the reference has no counterpart: it launches src/train.py:602-655 op by op) are laid out
+ * on `nstreams` ordinary streams with events on the cross-stream edges and re-issued with hipLaunchKernel / hipMemsetAsync /
+ * hipMemcpyAsync per replay.  create returns 0 (and sets unast_last_error) for graphs with node kinds it does not handle; the
+ * graph must outlive the plan.  info: {kernel nodes, memset nodes, memcpy nodes, cross-stream edges}. */
+int64_t unast_graph_plan_create(void* graph, int nstreams);
+int unast_graph_plan_info(int64_t plan, int* out4);
+int unast_graph_plan_replay(int64_t plan, hipStream_t origin);
+int unast_graph_plan_destroy(int64_t plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -267,8 +267,18 @@ def test_dgrad_through_transposed_presplit_weights():
     train.DEVICE = dev()
     utils.set_seed(3)
     args = make_args(num_layers=1, ae_steps=1, sp_steps=1, d_steps=1, cm_steps=0)
-    _, _, model, opt, _ = train.initialize_model(args)
-    st = model._store()
+    config.DGRAD_TRANSPOSED = True            # opt-in feature (config.py): the store builds the transposed copies when it is on
+    try:
+        _, _, model, opt, _ = train.initialize_model(args)
+        st = model._store()
+        _dgrad_T_body(st, opt)
+    finally:
+        config.DGRAD_TRANSPOSED = False
+
+
+def _dgrad_T_body(st, opt):
+    from unast_amd import ops, config
+    g = None
     st.sync_split()
     g = torch.Generator().manual_seed(5)
     P = st.phys

@@ -50,14 +50,21 @@ def _run_steps(graphed, use_disc, lr, n=6):
             train.train_step(losses, model, opt, sched, batches_for(i), i, args, defer_d_phase=True)
     if graphed:
         assert len(stepper.graphs) == 1
+        from unast_amd import graphed as G
+        rec = next(iter(stepper.graphs.values()))
+        if G.REPLAY == "streams":          # the executor understood every node of the captured step (no silent fallback)
+            assert rec.plan and rec.plan_info["kernels"] > 300 and rec.plan_info["cross_stream_edges"] > 10, rec.plan_info
+        else:
+            assert not rec.plan
         stepper.flush(losses)
     join_streams()
     torch.cuda.synchronize()
     return ({k: [float(x) for x in v] for k, v in losses.items()}, model._store().flat.detach().cpu().clone(), dict(opt._steps), opt.param_groups[0]["lr"])
 
 
+@pytest.mark.parametrize("replay", ["streams", "hipgraph"])
 @pytest.mark.parametrize("use_disc", [True, False])
-def test_graph_replay_and_eager_steps_agree(use_disc):
+def test_graph_replay_and_eager_steps_agree(use_disc, replay, monkeypatch):
     """Six outer steps with a different batch per sub-step and a learning-rate schedule (linear warm-up then decay, so every
     step has another lr) through train_step(defer_d_phase=True) and through GraphedTrainStep (two eager calls, one capture,
     three pure replays).  RNG sites off, so the two differ by accumulation-order noise only.
@@ -66,7 +73,8 @@ def test_graph_replay_and_eager_steps_agree(use_disc):
     (b) lr = 4e-4: the first three steps (eager generator phase, eager shifted step, first replay) agree to 3e-4, the later ones to 2e-2 --
         Adam moves elements with a near-zero gradient by +-lr on rounding noise and the text side's first layer amplifies that
         (DESIGN.md section 3); step counts, final lr and the parameters (to a few lr) agree."""
-    from unast_amd import utils
+    from unast_amd import utils, graphed
+    monkeypatch.setattr(graphed, "REPLAY", replay)       # "streams": csrc/graph_exec.cpp re-issues the captured nodes; "hipgraph": hipGraphLaunch
     utils.set_deterministic(True)
     (la, pa, sa, lra), (lb, pb, sb, lrb) = _run_steps(False, use_disc, 1e-7), _run_steps(True, use_disc, 1e-7)
     assert sa == sb and lra == lrb and set(la) == set(lb)

@@ -52,6 +52,8 @@ WGRAD_GROUP = os.environ.get("UNAST_WGRAD_GROUP", "1") != "0"
 # Attention backward as ONE pass (dK, dV and dQ; csrc/attention.hip attn_dkv_kernel<*,1>) instead of a dQ kernel + a dK/dV kernel.
 ATTN_FUSED_BWD = os.environ.get("UNAST_ATTN_FUSED_BWD", "1") != "0"
 
-# Input-gradient GEMMs (dX = dY W) read W^T from a transposed pre-split copy (K-contiguous operand, as the forward GEMMs read W)
-# instead of the untransposed weights through transposed LDS reads; 0 = the round-1 form (for A/B timing).
-DGRAD_TRANSPOSED = os.environ.get("UNAST_DGRAD_T", "1") != "0"
+# Input-gradient GEMMs (dX = dY W) can read W^T from a transposed pre-split copy (K-contiguous operand, as the forward GEMMs read
+# W) instead of the untransposed weights through transposed LDS reads.  Measured on MI355X at config 3: GEMM family 24.08 vs
+# 24.46 ms/step, step 32.9 vs 33.1 ms -- within noise (these launches are bound by their C / gate streams, not by the B path), so
+# it is OFF by default (it costs a second 68 MB weight copy and a refresh launch per optimizer phase); 1 = on.
+DGRAD_TRANSPOSED = os.environ.get("UNAST_DGRAD_T", "0") == "1"

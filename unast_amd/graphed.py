@@ -36,7 +36,13 @@ MAX_GRAPHS = 4
 
 
 class _Captured:
-    __slots__ = ("graph", "loss_keys", "loss_vec", "ranges")
+    __slots__ = ("graph", "loss_keys", "loss_vec", "ranges", "plan", "plan_info")
+
+
+# Replay of a captured step: "streams" = the captured nodes re-issued on ordinary HIP streams by csrc/graph_exec.cpp (default),
+# "hipgraph" = hipGraphLaunch of the instantiated graph.
+REPLAY = __import__("os").environ.get("UNAST_GRAPH_REPLAY", "streams")
+REPLAY_STREAMS = int(__import__("os").environ.get("UNAST_GRAPH_REPLAY_STREAMS", "6"))
 
 
 class GraphedTrainStep:
@@ -177,9 +183,22 @@ class GraphedTrainStep:
             rec.loss_keys = [k for k, _ in flat]
             rec.loss_vec = torch.stack([v.reshape(()) for _, v in flat]) if flat else None
         try:
-            rec.graph = _capture(fn)
+            rec.graph = _capture(fn, keep_graph=True)
         finally:
             T.SYNC_LOSSES = sync_flag
+        rec.plan, rec.plan_info = 0, None
+        if REPLAY == "streams":
+            from ._lib import lib
+            import ctypes
+            rec.plan = lib().unast_graph_plan_create(rec.graph.raw_cuda_graph(), REPLAY_STREAMS)
+            if rec.plan:
+                info = (ctypes.c_int * 4)()
+                lib().unast_graph_plan_info(rec.plan, ctypes.addressof(info))
+                rec.plan_info = dict(kernels=info[0], memsets=info[1], memcpys=info[2], cross_stream_edges=info[3], streams=REPLAY_STREAMS)
+            else:
+                rec.plan_info = dict(fallback="hipGraphLaunch: " + lib().unast_last_error().decode())
+        if not rec.plan:
+            rec.graph.instantiate()
         rec.ranges = list(self.opt.captured_ranges)
         self.graphs[sig] = rec
         return rec
@@ -193,7 +212,11 @@ class GraphedTrainStep:
             hyper[slot] = vals
         self.epoch += 1
         ops.set_step_state(self.epoch, hyper)
-        rec.graph.replay()
+        if rec.plan:
+            from ._lib import lib, check
+            check(lib().unast_graph_plan_replay(rec.plan, ops._stream()), "unast_graph_plan_replay")
+        else:
+            rec.graph.replay()
         self.opt._step_count = getattr(self.opt, "_step_count", 0) + 1       # what torch's LR schedulers look at
         if rec.loss_vec is not None:
             snap = rec.loss_vec.clone()

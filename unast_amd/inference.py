@@ -101,7 +101,7 @@ def _run_layers(layers, x, pro, pos_t, stop_lens):
 _CAPTURE_STREAM = {}
 
 
-def _capture(fn, pool=None):
+def _capture(fn, pool=None, keep_graph=False):
     """Captures fn() into a HIP graph on a dedicated stream.  torch.cuda.graph() is not used: on entry it collects garbage and
     EMPTIES the caching allocator (12 ms per capture here, and the train step that follows has to hipMalloc its whole working
     set again)."""
@@ -110,7 +110,7 @@ def _capture(fn, pool=None):
     if cs is None:
         cs = _CAPTURE_STREAM[dev] = torch.cuda.Stream()
     cur = torch.cuda.current_stream()
-    graph = torch.cuda.CUDAGraph()
+    graph = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()      # keep_graph: the hipGraph_t stays readable
     cs.wait_stream(cur)
     with torch.cuda.stream(cs):
         graph.capture_begin(**({"pool": pool} if pool is not None else {}))
