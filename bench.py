@@ -36,8 +36,8 @@ SUSTAINED_MFMA_TFLOPS = 1800.0          # v_mfma_f32_16x16x32_bf16 on random dat
 
 # Algorithmic TFLOP of one train step per GPU (full gen+disc step for c3/c5, generator-only for c2).
 STEP_TFLOP = {"c3": 4.875, "c2": 0.510, "c5": 15.940}
-ATTN_BWD_PRODUCTS = 7          # MFMA products the backward executes per (query, key) tile (5 algorithmic: S and dP are recomputed by the dK/dV kernel)
-ATTN_BWD_KERNEL = "attn_q_kernel<%(n)d,1> + attn_dkv_kernel<%(n)d>"
+ATTN_BWD_PRODUCTS = 5          # MFMA products the one-pass backward executes per (query, key) tile (7 in the two-kernel form: S and dP recomputed)
+ATTN_BWD_KERNEL = "attn_dkv_kernel<%(n)d,1> (dK, dV and dQ in one pass) + attn_delta_kernel"
 
 WORKLOADS = {
     # name: (B, Tt, Tm, L, use_discriminator)
@@ -363,6 +363,9 @@ def main():
             calls += sum(v[0] for v in gsu.values()); tot += sum(v[1] for v in gsu.values())
             fl += sum(group_flops(k) * v[0] for k, v in gsu.items()); by += sum(group_bytes(k) * v[0] for k, v in gsu.items())
         return dict(calls=calls, ms=tot, flops=fl, bytes=by)
+    global ATTN_BWD_PRODUCTS, ATTN_BWD_KERNEL
+    if not config.ATTN_FUSED_BWD:
+        ATTN_BWD_PRODUCTS, ATTN_BWD_KERNEL = 7, "attn_q_kernel<%(n)d,1> + attn_dkv_kernel<%(n)d,0> + attn_delta_kernel"
     fam = {n: family(iso, n) for n in ("gemm", "attn_fwd", "attn_bwd")}
     steps_iso = max(a.iso_steps, 1)
 

@@ -39,10 +39,13 @@ class _Captured:
     __slots__ = ("graph", "loss_keys", "loss_vec", "ranges", "plan", "plan_info")
 
 
-# Replay of a captured step: "streams" = the captured nodes re-issued on ordinary HIP streams by csrc/graph_exec.cpp (default),
-# "hipgraph" = hipGraphLaunch of the instantiated graph.
-REPLAY = __import__("os").environ.get("UNAST_GRAPH_REPLAY", "streams")
-REPLAY_STREAMS = int(__import__("os").environ.get("UNAST_GRAPH_REPLAY_STREAMS", "6"))
+# Replay of a captured step: "streams" = the captured nodes re-issued on ordinary HIP streams by csrc/graph_exec.cpp,
+# "hipgraph" = hipGraphLaunch of the instantiated graph, "auto" = by the shape of the graph: hipGraphLaunch is the cheaper
+# launch for a nearly linear graph (config 2, no discriminator: 16 cross-stream edges, 9.7 vs 10.5 ms/step) and the slower
+# executor for a heavily forked one (config 3: 190 cross-stream edges, 35-39 vs 32 ms/step).  MI355X, ROCm 7.2.
+REPLAY = __import__("os").environ.get("UNAST_GRAPH_REPLAY", "auto")
+REPLAY_STREAMS = int(__import__("os").environ.get("UNAST_GRAPH_REPLAY_STREAMS", "4"))       # 32.2 / 34.1 / 35.1 / 35.6 ms/step with 4 / 5 / 6 / 8 at config 3
+AUTO_MIN_CROSS_EDGES = 64
 
 
 class GraphedTrainStep:
@@ -187,16 +190,20 @@ class GraphedTrainStep:
         finally:
             T.SYNC_LOSSES = sync_flag
         rec.plan, rec.plan_info = 0, None
-        if REPLAY == "streams":
+        if REPLAY in ("streams", "auto"):
             from ._lib import lib
             import ctypes
             rec.plan = lib().unast_graph_plan_create(rec.graph.raw_cuda_graph(), REPLAY_STREAMS)
             if rec.plan:
                 info = (ctypes.c_int * 4)()
                 lib().unast_graph_plan_info(rec.plan, ctypes.addressof(info))
-                rec.plan_info = dict(kernels=info[0], memsets=info[1], memcpys=info[2], cross_stream_edges=info[3], streams=REPLAY_STREAMS)
+                rec.plan_info = dict(mode="streams", kernels=info[0], memsets=info[1], memcpys=info[2], cross_stream_edges=info[3], streams=REPLAY_STREAMS)
+                if REPLAY == "auto" and info[3] < AUTO_MIN_CROSS_EDGES:
+                    lib().unast_graph_plan_destroy(rec.plan)
+                    rec.plan = 0
+                    rec.plan_info["mode"] = "hipGraphLaunch (nearly linear graph)"
             else:
-                rec.plan_info = dict(fallback="hipGraphLaunch: " + lib().unast_last_error().decode())
+                rec.plan_info = dict(mode="hipGraphLaunch (fallback: %s)" % lib().unast_last_error().decode())
         if not rec.plan:
             rec.graph.instantiate()
         rec.ranges = list(self.opt.captured_ranges)
