@@ -1,16 +1,16 @@
+#!/bin/bash
+# Round-2 measurement pass on the MI355X box (repo root): tests, the default bench line, configs 2 and 5, then the rocprofv3
+# summaries that are copied into profiles/ (kernel stats of the bench command, HBM traffic PMC passes, attention PMC passes).
 set -x
-B="timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --launch eager"
-$B > gpurun_out/r2_b9_base.log 2> gpurun_out/r2_b9_base.err
-UNAST_AUTOGRAD_ST=1 $B > gpurun_out/r2_b9_st.log 2> gpurun_out/r2_b9_st.err
-UNAST_LN_FINALIZE_INLINE=1 $B > gpurun_out/r2_b9_lninl.log 2> gpurun_out/r2_b9_lninl.err
-UNAST_WGRAD_STREAMS=0 $B > gpurun_out/r2_b9_nows.log 2> gpurun_out/r2_b9_nows.err
-UNAST_WGRAD_GROUP_TARGET=768 $B > gpurun_out/r2_b9_t768.log 2> gpurun_out/r2_b9_t768.err
-$B > gpurun_out/r2_b9_base2.log 2> gpurun_out/r2_b9_base2.err
-UNAST_DDP_FORCE=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29561 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r2_b9_ddp.log 2> gpurun_out/r2_b9_ddp.err
-grep -o "\"ms_per_step\": [0-9.]*, \"higher\|host_enqueue_ms_per_step\": [0-9.]*" gpurun_out/r2_b9_*.log
+python -m pytest tests -m gpu -q > gpurun_out/r2_final_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r2_final_tests.log; tail -3 gpurun_out/r2_final_tests.log
+timeout -k 10 600 python bench.py > gpurun_out/r2_final_bench.json 2> gpurun_out/r2_final_bench.err; echo "bench rc=$?"
+timeout -k 10 300 python bench.py --workload c2 --no-cpu-baseline > gpurun_out/r2_final_c2.json 2> gpurun_out/r2_final_c2.err
+timeout -k 10 300 python bench.py --workload c5 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/r2_final_c5.json 2> gpurun_out/r2_final_c5.err
+timeout -k 10 300 python bench.py --no-cpu-baseline --launch eager --iso-detail > gpurun_out/r2_final_eager.json 2> gpurun_out/r2_final_eager.err
+timeout -k 10 300 python bench.py --no-cpu-baseline --launch graph > gpurun_out/r2_final_graph.json 2> gpurun_out/r2_final_graph.err
+grep -o "\"ms_per_step\": [0-9.]*, \"higher" gpurun_out/r2_final_*.json
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_r02a -- python3 /root/repo/bench.py --launch eager --no-cpu-baseline --steps 10 --warmup 3 > /root/repo/gpurun_out/prof_r02a.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_r02b -- python3 /root/repo/bench.py --launch eager --no-cpu-baseline --steps 10 --warmup 3 > /root/repo/gpurun_out/prof_r02b.log 2>&1
 cd /root/repo
-ls gpurun_out/prof_r02a/*/ | head
-bash tools/pmc_hbm_traffic.sh r02_pmc_hbm_traffic > gpurun_out/r2_pmc_traffic.log 2>&1; tail -20 gpurun_out/r2_pmc_traffic.log
-bash tools/pmc_attn.sh gpurun_out/pmc_attn_r02 > gpurun_out/r2_pmc_attn.log 2>&1; tail -60 gpurun_out/r2_pmc_attn.log
+bash tools/pmc_hbm_traffic.sh r02_pmc_hbm_traffic > gpurun_out/r2_pmc_traffic.log 2>&1; tail -16 gpurun_out/r2_pmc_traffic.log
+bash tools/pmc_attn.sh gpurun_out/pmc_attn_r02 > gpurun_out/r2_pmc_attn.log 2>&1; grep -n "avg launch\|MFMA busy\|SQ_VALU_MFMA_BUSY\|GRBM_GUI\|SQ_INSTS_VALU\|SQ_INSTS_MFMA" gpurun_out/r2_pmc_attn.log
