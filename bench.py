@@ -197,9 +197,10 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("UNAST_PREC", "bf16x3"), choices=["bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=int, default=110, help="seconds of CPU-oracle stepping (1 warm-up + up to 3 timed steps of the same batch)")
-    ap.add_argument("--launch", default=os.environ.get("UNAST_LAUNCH", "auto"), choices=["auto", "graph", "eager"],
+    ap.add_argument("--launch", default=os.environ.get("UNAST_LAUNCH"), choices=["auto", "graph", "eager"],
                     help="graph = replay the captured step (unast_amd.graphed), eager = one Python launch per kernel, auto = time a few untimed "
-                         "steps of each before the warm-up and keep the faster (graph replay wins where the host is the bound)")
+                         "steps of each before the warm-up and keep the faster.  Default: eager for the GPU-bound configurations (c3, c5: "
+                         "replay ties eager there, 32.9 vs 32.9 ms/step), auto for the host-bound ones (c2, tiny: 9.6 vs 17.2 ms/step)")
     ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
     ap.add_argument("--iso-detail", action="store_true", help="print the per-shape table of the isolated steps to stderr")
     ap.add_argument("--iso-steps", type=int, default=2, help="single-stream eager steps after the timed region whose GEMM / attention launches are timed with HIP events")
@@ -257,7 +258,7 @@ def main():
     losses = defaultdict(list)
 
     can_graph = a.cm_steps == 0 and not dist_on and not a.profile_ops and a.time_every == 0
-    launch = "eager" if (a.no_graph or not can_graph) else a.launch
+    launch = "eager" if (a.no_graph or not can_graph) else (a.launch or ("eager" if a.workload in ("c3", "c5") else "auto"))
     stepper = None
     auto_note = None
     if launch in ("graph", "auto"):

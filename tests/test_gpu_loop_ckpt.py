@@ -30,6 +30,27 @@ def test_train_loop_reduces_loss_and_follows_schedule(tmp_path):
     assert os.path.isfile(tmp_path / "ckpt" / "model_most_recent.ckpt")
 
 
+def test_train_loop_through_captured_graphs(tmp_path):
+    """train(args) with args.use_hip_graphs: the same loop (2 AE + 1 SP sub-steps accumulated, D phase, LR schedule,
+    checkpoints at epoch ends behind a flush of the pending discriminator phase) driven by GraphedTrainStep: one capture for
+    the fixed batch shape, every loss key gets its epoch_steps x sub-steps entries, the schedule is followed, it learns."""
+    from unast_amd import train, utils
+    train.DEVICE = D
+    utils.set_deterministic(False)
+    args = small_args(checkpoint_path=str(tmp_path / "ckpt"), epochs=3, epoch_steps=6, use_hip_graphs=True)
+    lrs, counts = [], []
+    model, hist = train.train(args, batch_getter=train.SyntheticBatchGetter(args, t_text=12, t_mel=32, ragged=True),
+                              on_epoch_end=lambda e, m, o, h: lrs.append(o.param_groups[0]["lr"]))
+    assert len(hist) == 3 and set(hist[0]) == {"t_ae", "s_ae", "d_ae", "asr_", "tts_", "sp_d", "d"}
+    assert all(v == v and abs(v) < 1e6 for h in hist for v in h.values())
+    assert hist[-1]["s_ae"] < hist[0]["s_ae"] and hist[-1]["tts_"] < hist[0]["tts_"]
+    exp = [args.lr * (s / 8 ** 1.5 if s < 8 else 1 / s ** 0.5) for s in (6, 12, 18)]
+    assert all(abs(a - b) < 1e-9 for a, b in zip(lrs, exp)), (lrs, exp)
+    assert os.path.isfile(tmp_path / "ckpt" / "model_most_recent.ckpt")
+    for p in model.parameters():
+        assert torch.isfinite(p).all()
+
+
 def test_checkpoint_roundtrip_and_torch_adamw_format(tmp_path):
     from collections import defaultdict
     from unast_amd import train, utils

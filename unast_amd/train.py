@@ -501,13 +501,25 @@ def train(args, batch_getter=None, on_epoch_end=None, valid_dataloader=None):
     max_obj_steps = max(args.ae_steps, cm_steps, args.sp_steps, args.d_steps if args.use_discriminator else 0)
     accum_steps = args.ae_steps + cm_steps + args.sp_steps
     history = []
+    # args.use_hip_graphs (not a reference key; default off): the body of the hot loop as a captured graph (unast_amd.graphed),
+    # re-captured per input shape -- for fixed-shape batches (bucketed / padded loaders) on host-bound configurations.
+    stepper = None
+    if getattr(args, "use_hip_graphs", False) and cm_steps == 0:
+        from .graphed import GraphedTrainStep
+        stepper = GraphedTrainStep(model, optimizer, scheduler, args)
     for epoch in range(s_epoch, args.epochs):
         losses = defaultdict(list)
         for s in range(args.epoch_steps):
             model.train()
+            base = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps
+            if stepper is not None:
+                batches = dict(unsup=[batch_getter.get_unsupervised_batch() for _ in range(args.ae_steps)],
+                               sup=[batch_getter.get_supervised_batch() for _ in range(args.sp_steps)],
+                               disc=[batch_getter.get_discriminator_batch() for _ in range(args.d_steps if args.use_discriminator else 0)])
+                stepper(losses, batches, base)             # includes scheduler.step()
+                continue
             if args.use_discriminator:
                 freeze_model_parameters(model.discriminator)
-            base = epoch * args.epoch_steps * max_obj_steps + s * max_obj_steps
             subs = [(train_ae_step, batch_getter.get_unsupervised_batch, si) for si in range(args.ae_steps)]
             subs += [(train_cm_step, batch_getter.get_unsupervised_batch, si) for si in range(cm_steps)]
             subs += [(train_sp_step, batch_getter.get_supervised_batch, si) for si in range(args.sp_steps)]
@@ -524,6 +536,8 @@ def train(args, batch_getter=None, on_epoch_end=None, valid_dataloader=None):
                 optimizer_step(model, optimizer, args, defer=True)
             if scheduler is not None:
                 scheduler.step()
+        if stepper is not None:
+            stepper.flush(losses)                  # the last step's discriminator phase, before losses / checkpoints / evaluation
         join_streams()                             # the last D phase may still be running on its own stream
         history.append(log_loss_metrics(losses, epoch))
         if not all(v == v and abs(v) < float("inf") for v in history[-1].values()):
