@@ -42,7 +42,10 @@ const char* unast_arch(void);
  * tile_wn: 2 = 128x128 tile / 4 waves, 8 = 128x128 tile / 8 waves, 4 = 128x256 tile / 8 waves; 0 lets the library
  *           choose (8 waves for forward / dgrad forms, 4 waves for weight gradients).
  * b_presplit: B points into a copy of the weights kept in the pre-split operand format written by unast_adamw /
- *           unast_split_f32 (same byte offsets as the fp32 weights), so the kernel does not re-split them per row panel. */
+ *           unast_split_f32 (same byte offsets as the fp32 weights), so the kernel does not re-split them per row panel.
+ * out_split: C is stored in that same format (per 4 consecutive columns one 16-byte chunk [hi x4 | lo x4] of bf16 at the fp32
+ *           byte offset): the in-projection outputs Q / K / V and the out-projection's input gradient dO, which only the
+ *           attention kernels read (qkv_split there); needs N % 4 == 0, beta = 0, no split-K. */
 int unast_gemm(int a_mode, int b_mode, int nsplit,
                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                int M, int N, int K, int kb_valid,
@@ -51,23 +54,25 @@ int unast_gemm(int a_mode, int b_mode, int nsplit,
                float alpha, int beta, int act,
                float drop_p, unsigned int seed, unsigned int stream_id,
                int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, int tile_wn, int b_presplit,
-               hipStream_t stream);
+               int out_split, hipStream_t stream);
 
 /* Fused multi-head attention core (head_dim 64), flash-style.  Replaces the softmax(QK^T/sqrt(d)+mask) -> dropout -> V
  * core of torch.nn.MultiheadAttention inside torch.nn.TransformerEncoderLayer/DecoderLayer
  * (src/module.py:273-274, 286-287; masks built at src/network.py:404-415, src/utils.py:77-83).
  * Q [B,Tq,ldq], K/V [B,Tk,ld*]: head h occupies columns [64h, 64h+64).  Keys >= lens_k[b] are masked (lens_k may be
- * NULL); causal masks key > query.  O [B,Tq,ldo] (heads concatenated), LSE [B,H,Tq] saved for the backward. */
+ * NULL); causal masks key > query.  O [B,Tq,ldo] (heads concatenated), LSE [B,H,Tq] saved for the backward.
+ * qkv_split = 1: Q, K, V (and dO in the backward) are in the pre-split operand format a unast_gemm with out_split = 1 wrote
+ * (same shapes and strides; per 4 consecutive columns one 16-byte chunk [hi x4 | lo x4] of bf16). */
 int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                    float* LSE, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
-                   float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);
+                   float drop_p, unsigned int seed, unsigned int stream_id, int qkv_split, hipStream_t stream);
 /* Backward of the above (autograd of the same torch call sites): dQ, dK, dV from dO; delta_ws is [B,H,Tq] scratch.
  * fused = 1: one pass over the (query, key) tiles produces all three (dS crosses LDS for dQ, key blocks are summed into dQ with
  * fp32 atomics, dQ is zeroed first); fused = 0: a dQ kernel and a dK/dV kernel that each recompute the probabilities. */
 int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                    const float* dO, int lddo, const float* LSE, float* delta_ws, float* dQ, int lddq, float* dK, int lddk,
                    float* dV, int lddv, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
-                   float drop_p, unsigned int seed, unsigned int stream_id, int fused, hipStream_t stream);
+                   float drop_p, unsigned int seed, unsigned int stream_id, int fused, int qkv_split, hipStream_t stream);
 
 /* LayerNorm(eps) of the post-LN transformer blocks (norm1/2/3 inside torch layers, src/module.py:273-274,286-287).
  * bwd: dz (and optionally dz_drop = dz * dropout mask/(1-p), the gradient of the dropped sub-layer output);

@@ -93,6 +93,51 @@ def test_attention_backward_one_pass_equals_two_kernels(B, Tq, Tk, causal, p):
     assert relerr(res[1][0], res[0][0].cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("B,Tq,Tk,causal,p", [(2, 200, 200, True, 0.1), (2, 150, 37, False, 0.0), (1, 33, 300, False, 0.1)])
+def test_attention_on_presplit_operands(B, Tq, Tk, causal, p):
+    """Q / K / V / dO handed over in the pre-split format (what the projections' out_split epilogue stores; produced here by
+    unast_split_f32) give the same O, LSE, dQ, dK, dV as the fp32 operands: the same hi/lo values enter the MFMAs, only the
+    place of the score scale differs (in the exponent's fma instead of in Q)."""
+    from unast_amd import ops
+    H, E = 4, 256
+    g = torch.Generator().manual_seed(B * 77 + Tq)
+    q = torch.randn(B * Tq, E, generator=g).to(D); k = torch.randn(B * Tk, E, generator=g).to(D); v = torch.randn(B * Tk, E, generator=g).to(D)
+    dO = torch.randn(B * Tq, E, generator=g).to(D)
+    lens = torch.randint(max(1, Tk // 2), Tk + 1, (B,), generator=g).to(torch.int32).to(D)
+    sp = [torch.empty_like(t) for t in (q, k, v, dO)]
+    for src, dst in zip((q, k, v, dO), sp):
+        ops.split_f32(src.view(-1), dst.view(-1))
+    res = []
+    for split in (False, True):
+        Q_, K_, V_, dO_ = sp if split else (q, k, v, dO)
+        o = torch.empty(B * Tq, E, device=D); lse = torch.empty(B, H, Tq, device=D)
+        ops.attn_fwd(Q_, K_, V_, o, lse, lens, B, H, Tq, Tk, causal, drop_p=p, seed=11, stream_id=2, qkv_split=split)
+        ws = torch.empty(B, H, Tq, device=D)
+        dq = torch.empty(B * Tq, E, device=D); dk = torch.empty(B * Tk, E, device=D); dv = torch.empty(B * Tk, E, device=D)
+        ops.attn_bwd(Q_, K_, V_, o, dO_, lse, ws, dq, dk, dv, lens, B, H, Tq, Tk, causal, drop_p=p, seed=11, stream_id=2, qkv_split=split)
+        res.append((o, lse, dq, dk, dv))
+    for a, b, name in zip(res[1], res[0], ("O", "LSE", "dQ", "dK", "dV")):
+        assert relerr(a, b.cpu()) < 3e-5, name
+
+
+def test_gemm_out_split_equals_split_of_fp32_output():
+    """unast_gemm out_split = 1 stores exactly split_f32(fp32 result): bias / residual epilogue, column slices of a wider buffer."""
+    from unast_amd import ops
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 640, 768, 256
+    x = torch.randn(M, K, generator=g).to(D); W = (torch.randn(N, K, generator=g) * 0.1).to(D); b = torch.randn(N, generator=g).to(D)
+    y = torch.empty(M, N, device=D); ys = torch.empty(M, N, device=D); ref = torch.empty(M, N, device=D)
+    ops.linear_fwd(x, W, b, y)
+    ops.linear_fwd(x, W, b, ys, out_split=True)
+    ops.split_f32(y.view(-1), ref.view(-1))
+    assert torch.equal(ys.view(torch.int32), ref.view(torch.int32))
+    dx = torch.empty(M, K, device=D); dxs = torch.empty(M, K, device=D); refx = torch.empty(M, K, device=D)
+    ops.linear_dgrad(y, W, dx)
+    ops.linear_dgrad(y, W, dxs, out_split=True)
+    ops.split_f32(dx.view(-1), refx.view(-1))
+    assert torch.equal(dxs.view(torch.int32), refx.view(torch.int32))
+
+
 def test_attention_dropout_consistency():
     """Dropout on P: forward keep-rate, determinism, and backward uses the same mask (finite-difference check on V)."""
     from unast_amd import ops

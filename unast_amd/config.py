@@ -57,3 +57,7 @@ ATTN_FUSED_BWD = os.environ.get("UNAST_ATTN_FUSED_BWD", "1") != "0"
 # 24.46 ms/step, step 32.9 vs 33.1 ms -- within noise (these launches are bound by their C / gate streams, not by the B path), so
 # it is OFF by default (it costs a second 68 MB weight copy and a refresh launch per optimizer phase); 1 = on.
 DGRAD_TRANSPOSED = os.environ.get("UNAST_DGRAD_T", "0") == "1"
+
+# The in-projections write Q / K / V -- and the out-projection's input-gradient GEMM writes dO -- in the pre-split operand format;
+# the attention kernels then stage K/V (forward) and Q/dO (backward) tiles without fp32 -> hi/lo conversions.  0 = fp32 (A/B).
+ATTN_PRESPLIT = os.environ.get("UNAST_ATTN_PRESPLIT", "1") != "0"

@@ -37,6 +37,7 @@ struct AttnParams {
     int B, H, Tq, Tk, causal;
     float scale;
     uint32_t drop_thresh; float drop_scale; uint32_t seed, stream;
+    int qkv_split;                     // Q, K, V (and dO) arrive in the pre-split operand format (GEMM out_split): no fp32 -> hi/lo conversion here
 };
 
 template <int NSPLIT>
@@ -47,6 +48,26 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, bf16x8_
     u32x4 h = {h0[0], h0[1], h1[0], h1[1]}, l = {l0[0], l0[1], l1[0], l1[1]};
     hi = __builtin_bit_cast(bf16x8_t, h);
     lo = __builtin_bit_cast(bf16x8_t, l);
+}
+
+// 8 consecutive operand elements at `src` -> hi/lo fragments: fp32 values (optionally scaled) are split here; pre-split data
+// ([hi x4 | lo x4] per 16-byte chunk) is only re-packed.  `ok` false -> zeros.
+template <int NSPLIT>
+__device__ __forceinline__ void load_frag8(const float* __restrict__ src, bool ok, bool split_in, float pre_scale, bf16x8_t& hi, bf16x8_t& lo) {
+    float4 a = make_float4(0, 0, 0, 0), c = a;
+    if (ok) {
+        a = *reinterpret_cast<const float4*>(src);
+        c = *reinterpret_cast<const float4*>(src + 4);
+    }
+    if (split_in) {
+        u32x4 h = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(c.x), __float_as_uint(c.y)};
+        u32x4 l = {__float_as_uint(a.z), __float_as_uint(a.w), __float_as_uint(c.z), __float_as_uint(c.w)};
+        hi = __builtin_bit_cast(bf16x8_t, h);
+        lo = __builtin_bit_cast(bf16x8_t, l);
+    } else {
+        a.x *= pre_scale; a.y *= pre_scale; a.z *= pre_scale; a.w *= pre_scale; c.x *= pre_scale; c.y *= pre_scale; c.z *= pre_scale; c.w *= pre_scale;
+        split8<NSPLIT>(a, c, hi, lo);
+    }
 }
 
 // 8 fp32 values (two accumulator quads) -> hi/lo bf16x8 operand fragments
@@ -94,13 +115,17 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ src, int ld,
     }
 }
 template <int NROWS, int NSPLIT>
-__device__ __forceinline__ void tile_store(const float4 (&r)[NROWS / 16], unsigned char* hi_img, unsigned char* lo_img, int t) {
+__device__ __forceinline__ void tile_store(const float4 (&r)[NROWS / 16], unsigned char* hi_img, unsigned char* lo_img, int t, bool split_in = false) {
 #pragma unroll
     for (int i = 0; i < NROWS / 16; ++i) {
         const int idx = t + 256 * i;
         const int row = idx >> 4, dq = (idx & 15) * 4;
         u32x2 hi, lo;
-        split4<NSPLIT>(r[i], hi, lo);
+        if (split_in) {     // already [hi x4 | lo x4]
+            hi[0] = __float_as_uint(r[i].x); hi[1] = __float_as_uint(r[i].y); lo[0] = __float_as_uint(r[i].z); lo[1] = __float_as_uint(r[i].w);
+        } else {
+            split4<NSPLIT>(r[i], hi, lo);
+        }
         *reinterpret_cast<u32x2*>(hi_img + img_off(row, dq)) = hi;
         if (NSPLIT == 3) *reinterpret_cast<u32x2*>(lo_img + img_off(row, dq)) = lo;
     }
@@ -149,6 +174,10 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
     const float sc = p.scale * LOG2E;
 
     // per-wave query-side operand fragments: lane holds X[q = q0+16qs+l15][d = 32kst+8g..+7]
+    // Scores are wanted in log2 units: fp32 Q is multiplied by scale*log2(e) before it is split; pre-split Q cannot be, so
+    // there the factor rides in the exponent's fma (ssc) instead -- the same instruction count either way.
+    const bool split_in = p.qkv_split != 0;
+    const float ssc = split_in ? sc : 1.f;
     bf16x8_t qf[2][2][PARTS], dof[2][2][PARTS];
     float lse2[2] = {0.f, 0.f}, delta[2] = {0.f, 0.f};
 #pragma unroll
@@ -157,26 +186,12 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
         const bool ok = q < p.Tq;
 #pragma unroll
         for (int kst = 0; kst < 2; ++kst) {
-            float4 a = make_float4(0, 0, 0, 0), c = a;
-            if (ok) {
-                const float* src = Qb + (size_t)q * p.ldq + 32 * kst + 8 * g;
-                a = *reinterpret_cast<const float4*>(src);
-                c = *reinterpret_cast<const float4*>(src + 4);
-                // scores are wanted in log2 units: fold scale*log2(e) into Q once instead of scaling every score
-                a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc; c.x *= sc; c.y *= sc; c.z *= sc; c.w *= sc;
-            }
             bf16x8_t hi, lo;
-            split8<NSPLIT>(a, c, hi, lo);
+            load_frag8<NSPLIT>(Qb + (size_t)q * p.ldq + 32 * kst + 8 * g, ok, split_in, sc, hi, lo);
             qf[qs][kst][0] = hi;
             if (PARTS == 2) qf[qs][kst][PARTS - 1] = lo;
             if (MODE == 1) {
-                a = make_float4(0, 0, 0, 0); c = a;
-                if (ok) {
-                    const float* src = p.dO + ((size_t)b * p.Tq + q) * p.lddo + h * HD + 32 * kst + 8 * g;
-                    a = *reinterpret_cast<const float4*>(src);
-                    c = *reinterpret_cast<const float4*>(src + 4);
-                }
-                split8<NSPLIT>(a, c, hi, lo);
+                load_frag8<NSPLIT>(p.dO + ((size_t)b * p.Tq + q) * p.lddo + h * HD + 32 * kst + 8 * g, ok, split_in, 1.f, hi, lo);
                 dof[qs][kst][0] = hi;
                 if (PARTS == 2) dof[qs][kst][PARTS - 1] = lo;
             }
@@ -206,8 +221,8 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
         tile_load<64>(Vb, p.ldv, min(64, p.Tk), rv, t);
     }
     for (int kt = 0; kt < nkt; ++kt) {
-        tile_store<64, NSPLIT>(rk, sK[0], sK[PARTS - 1], t);
-        tile_store<64, NSPLIT>(rv, sV[0], sV[PARTS - 1], t);
+        tile_store<64, NSPLIT>(rk, sK[0], sK[PARTS - 1], t, split_in);
+        tile_store<64, NSPLIT>(rv, sV[0], sV[PARTS - 1], t, split_in);
         __syncthreads();
         if (kt + 1 < nkt) {
             const int kr = (kt + 1) * 64;
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
                         }
                     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
                     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                    const float mnew = fmaxf(m[qs], tmax);
+                    const float mnew = fmaxf(m[qs], tmax * ssc);
                     const float alpha = __builtin_amdgcn_exp2f(m[qs] - mnew);
                     m[qs] = mnew;
                     mref = mnew;
@@ -286,11 +301,11 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
                         float pv;
                         if (MODE == 0) {
                             const float v = s[ks][qs][r];
-                            pv = __builtin_amdgcn_exp2f(v - mref);            // masked entries: exp2(-1e30 - m) = 0
+                            pv = __builtin_amdgcn_exp2f(__builtin_fmaf(v, ssc, -mref));      // masked entries: exp2(-1e30 * ssc - m) = 0
                             rs += pv;
                             s[ks][qs][r] = keep ? pv * p.drop_scale : 0.f;
                         } else {
-                            pv = __builtin_amdgcn_exp2f(s[ks][qs][r] - mref);
+                            pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ks][qs][r], ssc, -mref));
                             if (MASKED) {
                                 const int key = key0 + r;
                                 const bool valid = key < klen && (!p.causal || key <= q) && q < p.Tq;
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
 // the dS accumulators, so dS crosses LDS once: every wave writes its [32 keys x 32 queries] block (the hi/lo bf16 words it packs
 // for the dK product anyway) into a [128 keys][2 x 32 queries] image (two query tiles side by side = double buffer), and in the
 // NEXT iteration -- behind the barrier that is there anyway -- wave w multiplies the whole 128-key column block by the
-// pre-scaled K image: dQ[32 q x 16 d (slice w)] = dS^T-fragments (transposed reads) x K-fragments (transposed reads, same
+// K image: dQ[32 q x 16 d (slice w)] = dS^T-fragments (transposed reads) x K-fragments (transposed reads, same
 // key permutation).  The result is the workgroup's share of dQ; key blocks are summed with fp32 atomics (each wave-instruction
 // adds 4 rows x 64 contiguous bytes), dQ is zeroed by the caller.
 template <int NSPLIT, int FUSE_DQ>
@@ -386,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
     const float* delb = p.Delta + ((size_t)b * p.H + h) * p.Tq;
 
     // key-side operand fragments in registers: lane holds X[key = k0+16ks+l15][d = 32kst+8g..+7]
+    const bool split_in = p.qkv_split != 0;
     bf16x8_t kf[2][2][PARTS], vf[2][2][PARTS];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -393,17 +409,10 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
         const bool ok = key < p.Tk;
 #pragma unroll
         for (int kst = 0; kst < 2; ++kst) {
-            float4 a = make_float4(0, 0, 0, 0), c = a, a2 = a, c2 = a;
-            if (ok) {
-                const float* src = Kb + (size_t)key * p.ldk + 32 * kst + 8 * g;
-                a = *reinterpret_cast<const float4*>(src); c = *reinterpret_cast<const float4*>(src + 4);
-                const float* sv = Vb + (size_t)key * p.ldv + 32 * kst + 8 * g;
-                a2 = *reinterpret_cast<const float4*>(sv); c2 = *reinterpret_cast<const float4*>(sv + 4);
-            }
             bf16x8_t hi, lo;
-            split8<NSPLIT>(a, c, hi, lo);
+            load_frag8<NSPLIT>(Kb + (size_t)key * p.ldk + 32 * kst + 8 * g, ok, split_in, 1.f, hi, lo);
             kf[ks][kst][0] = hi; if (PARTS == 2) kf[ks][kst][PARTS - 1] = lo;
-            split8<NSPLIT>(a2, c2, hi, lo);
+            load_frag8<NSPLIT>(Vb + (size_t)key * p.ldv + 32 * kst + 8 * g, ok, split_in, 1.f, hi, lo);
             vf[ks][kst][0] = hi; if (PARTS == 2) vf[ks][kst][PARTS - 1] = lo;
         }
     }
@@ -418,12 +427,10 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
     const int qt_begin = p.causal ? (kblk / 32) : 0;
     const int qt_end = block_live ? (p.Tq + 31) / 32 : qt_begin;
     float4 rq[2], rd[2];
-    if (FUSE_DQ && qt_begin < qt_end) {          // the workgroup's 128 keys, pre-scaled, as the B operand of the dQ product
+    if (FUSE_DQ && qt_begin < qt_end) {          // the workgroup's 128 keys as the B operand of the dQ product (scale applied to dQ itself)
         float4 rk8[8];
         tile_load<128>(Kb + (size_t)kblk * p.ldk, p.ldk, min(128, p.Tk - kblk), rk8, t);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { rk8[i].x *= p.scale; rk8[i].y *= p.scale; rk8[i].z *= p.scale; rk8[i].w *= p.scale; }
-        tile_store<128, NSPLIT>(rk8, sKs[0], sKs[PARTS - 1], t);
+        tile_store<128, NSPLIT>(rk8, sKs[0], sKs[PARTS - 1], t, split_in);
     }
     if (qt_begin < qt_end) {
         tile_load<32>(Qb + (size_t)qt_begin * 32 * p.ldq, p.ldq, min(32, p.Tq - qt_begin * 32), rq, t);
@@ -449,12 +456,12 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = qtile * 32 + 16 * qs + 4 * g + r;
-                if (q < p.Tq) unsafeAtomicAdd(dqb + (size_t)q * p.ldo, dq[qs][r]);
+                if (q < p.Tq) unsafeAtomicAdd(dqb + (size_t)q * p.ldo, dq[qs][r] * p.scale);
             }
     };
     for (int qt = qt_begin; qt < qt_end; ++qt) {
-        tile_store<32, NSPLIT>(rq, sQ[0], sQ[PARTS - 1], t);
-        tile_store<32, NSPLIT>(rd, sD[0], sD[PARTS - 1], t);
+        tile_store<32, NSPLIT>(rq, sQ[0], sQ[PARTS - 1], t, split_in);
+        tile_store<32, NSPLIT>(rd, sD[0], sD[PARTS - 1], t, split_in);
         __syncthreads();
         if (FUSE_DQ && qt > qt_begin) dq_phase(qt - 1, (qt - 1) & 1);
         if (qt + 1 < qt_end) {
@@ -569,7 +576,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
 // Delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]; one wave per (b,q) row of H*64 = 256 columns (H == 4) or generic H.
 // zero_dq (may be NULL): the same rows of dQ are cleared on the way (the one-pass backward accumulates into dQ with atomics).
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dO, int lddo, const float* __restrict__ O, int ldo,
-                                                         float* __restrict__ delta, int rows, int Tq, int H, float* __restrict__ zero_dq, int lddq) {
+                                                         float* __restrict__ delta, int rows, int Tq, int H, float* __restrict__ zero_dq, int lddq,
+                                                         int do_split) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -580,6 +588,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
         if (h < H) {
             const int c = h * HD + (lane & 15) * 4;
             float4 a = *reinterpret_cast<const float4*>(dO + (size_t)row * lddo + c);
+            if (do_split) {         // [hi x4 | lo x4] -> the 4 values (hi + lo, to the ~16 bits the products see anyway)
+                const uint32_t h0 = __float_as_uint(a.x), h1 = __float_as_uint(a.y), l0 = __float_as_uint(a.z), l1 = __float_as_uint(a.w);
+                a.x = __uint_as_float(h0 << 16) + __uint_as_float(l0 << 16);
+                a.y = __uint_as_float(h0 & 0xFFFF0000u) + __uint_as_float(l0 & 0xFFFF0000u);
+                a.z = __uint_as_float(h1 << 16) + __uint_as_float(l1 << 16);
+                a.w = __uint_as_float(h1 & 0xFFFF0000u) + __uint_as_float(l1 & 0xFFFF0000u);
+            }
             float4 o = *reinterpret_cast<const float4*>(O + (size_t)row * ldo + c);
             s = (a.x * o.x + a.y * o.y) + (a.z * o.z + a.w * o.w);
             if (zero_dq) *reinterpret_cast<float4*>(zero_dq + (size_t)row * lddq + c) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -595,7 +610,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 static int fill_common(AttnParams& p, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const int* lens_k,
-                       int B, int H, int Tq, int Tk, int head_dim, int causal, float scale, float drop_p, unsigned seed, unsigned stream_id) {
+                       int B, int H, int Tq, int Tk, int head_dim, int causal, float scale, float drop_p, unsigned seed, unsigned stream_id, int qkv_split) {
     UNAST_REQUIRE(Q && K && V, "unast_attn: null Q/K/V");
     UNAST_REQUIRE(head_dim == HD, "unast_attn: this build supports head_dim=%d only (got %d)", HD, head_dim);
     UNAST_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "unast_attn: bad dims");
@@ -604,15 +619,16 @@ static int fill_common(AttnParams& p, const float* Q, int ldq, const float* K, i
     p.Q = Q; p.K = K; p.V = V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.lens_k = lens_k;
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.causal = causal; p.scale = scale;
     p.drop_thresh = drop_threshold(drop_p); p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.seed = seed; p.stream = stream_id;
+    p.qkv_split = qkv_split;
     p.O = nullptr; p.LSE = nullptr; p.dO = nullptr; p.Delta = nullptr; p.dK = nullptr; p.dV = nullptr; p.ldo = p.lddo = p.lddk = p.lddv = 0;
     return UNAST_OK;
 }
 
 extern "C" int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                               float* LSE, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
-                              float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream) {
+                              float drop_p, unsigned int seed, unsigned int stream_id, int qkv_split, hipStream_t stream) {
     AttnParams p;
-    int rc = fill_common(p, Q, ldq, K, ldk, V, ldv, lens_k, B, H, Tq, Tk, head_dim, causal, scale, drop_p, seed, stream_id);
+    int rc = fill_common(p, Q, ldq, K, ldk, V, ldv, lens_k, B, H, Tq, Tk, head_dim, causal, scale, drop_p, seed, stream_id, qkv_split);
     if (rc) return rc;
     UNAST_REQUIRE(O && LSE && al16(O) && (ldo & 3) == 0, "unast_attn_fwd: bad output");
     UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_attn_fwd: nsplit must be 1 or 3");
@@ -626,16 +642,16 @@ extern "C" int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* 
 extern "C" int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                               const float* dO, int lddo, const float* LSE, float* delta_ws, float* dQ, int lddq, float* dK, int lddk,
                               float* dV, int lddv, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
-                              float drop_p, unsigned int seed, unsigned int stream_id, int fused, hipStream_t stream) {
+                              float drop_p, unsigned int seed, unsigned int stream_id, int fused, int qkv_split, hipStream_t stream) {
     AttnParams p;
-    int rc = fill_common(p, Q, ldq, K, ldk, V, ldv, lens_k, B, H, Tq, Tk, head_dim, causal, scale, drop_p, seed, stream_id);
+    int rc = fill_common(p, Q, ldq, K, ldk, V, ldv, lens_k, B, H, Tq, Tk, head_dim, causal, scale, drop_p, seed, stream_id, qkv_split);
     if (rc) return rc;
     UNAST_REQUIRE(O && dO && LSE && delta_ws && dQ && dK && dV, "unast_attn_bwd: null pointer");
     UNAST_REQUIRE(al16(O) && al16(dO) && al16(dQ) && al16(dK) && al16(dV) && ((ldo | lddo | lddq | lddk | lddv) & 3) == 0,
                   "unast_attn_bwd: operands must be 16-byte aligned with ld%%4==0");
     UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_attn_bwd: nsplit must be 1 or 3");
     const int rows = B * Tq;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, dO, lddo, O, ldo, delta_ws, rows, Tq, H, fused ? dQ : nullptr, lddq);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, dO, lddo, O, ldo, delta_ws, rows, Tq, H, fused ? dQ : nullptr, lddq, qkv_split);
     p.dO = dO; p.lddo = lddo; p.LSE = const_cast<float*>(LSE); p.Delta = delta_ws;
     p.O = dQ; p.ldo = lddq; p.dK = dK; p.dV = dV; p.lddk = lddk; p.lddv = lddv;
     dim3 gq(xcd_grid((Tq + 127) / 128, B * H)), gk(xcd_grid((Tk + 127) / 128, B * H));

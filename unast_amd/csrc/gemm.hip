@@ -39,6 +39,7 @@ struct GemmParams {
     int kb_valid;                                     // rows of a row-contiguous B that exist (K may be zero-padded above it)
     float* rowsum_a;                                  // optional: rowsum_a[m] += sum_k A[m][k] (bias gradient fused into wgrad)
     int group;                                        // launched as one problem of a grouped weight-gradient launch (split-K tile map, slabs)
+    int out_split;                                    // store C in the pre-split operand format (16-B chunks [hi x4 | lo x4]) for the attention kernels
 };
 
 __device__ __forceinline__ int swz_h(int row) { return (0x1320 >> (((row >> 2) & 3) << 2)) & 3; }
@@ -169,7 +170,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                     float4 c = *reinterpret_cast<const float4*>(cp);
                     o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
                 }
-                *reinterpret_cast<float4*>(cp) = o;
+                if (p.out_split) *reinterpret_cast<uint4*>(cp) = split_chunk(o);
+                else *reinterpret_cast<float4*>(cp) = o;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GroupParams gp
     p.alpha = 1.f; p.beta = 1; p.act = 0; p.drop_thresh = 0u; p.drop_scale = 1.f; p.seed = 0u; p.stream = 0u;
     p.kchunk = it.kchunk; p.atomic = 0; p.tiles_m = it.tiles_m; p.tiles_n = it.tiles_n; p.nsplitk = it.nsplitk;
     p.slab = it.slab; p.ld_slab = it.ld_slab; p.slab_stride = (size_t)it.M * it.ld_slab;
-    p.kb_valid = it.K; p.rowsum_a = it.rowsum_a; p.group = 1;
+    p.kb_valid = it.K; p.rowsum_a = it.rowsum_a; p.group = 1; p.out_split = 0;
     gemm_body<OP_RC, OP_RC, NSPLIT, 2, 2, FLAGS>(p, b - gp.base[i]);
 }
 
@@ -587,7 +589,7 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
                           float alpha, int beta, int act,
                           float drop_p, unsigned int seed, unsigned int stream_id,
                           int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, int tile_wn, int b_presplit,
-                          hipStream_t stream) {
+                          int out_split, hipStream_t stream) {
     UNAST_REQUIRE(A && B && C, "unast_gemm: null operand");
     UNAST_REQUIRE(!b_presplit || (a_mode == OP_KC || a_mode == OP_KC_CONV), "unast_gemm: a pre-split B is a weight (forward / dgrad forms only)");
     UNAST_REQUIRE(M > 0 && N > 0 && K > 0, "unast_gemm: bad dims M=%d N=%d K=%d", M, N, K);
@@ -610,7 +612,8 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     p.bias = bias; p.R = R; p.ldr = ldr; p.G = G; p.ldg = ldg; p.gate_scale = gate_scale;
     p.alpha = alpha; p.beta = beta; p.act = act;
     p.drop_thresh = drop_threshold(drop_p); p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    p.seed = seed; p.stream = stream_id; p.group = 0;
+    p.seed = seed; p.stream = stream_id; p.group = 0; p.out_split = out_split;
+    UNAST_REQUIRE(!out_split || ((N & 3) == 0 && (ldc & 3) == 0 && beta == 0 && splitk == 1), "unast_gemm: out_split needs N %% 4 == 0, ldc %% 4 == 0, beta = 0, no split-K");
     // tile width: 128x256 when N is wide enough and the grid still fills the chip; `tile_wn` (2/4) overrides, 0 = auto
     int wn = tile_wn;
     if (wn != 2 && wn != 4 && wn != 8) {

@@ -9,7 +9,7 @@ import math
 
 import torch
 
-from . import ops
+from . import config, ops
 from .engine import Var, acc
 from .utils import is_deterministic
 
@@ -70,19 +70,22 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
     Wo, bo = cx.P[pre_attn + "out_proj.weight"], cx.P[pre_attn + "out_proj.bias"]
     p = cx.p(drop)
     s_attn, s_out = cx.stream(), cx.stream()
+    # Q / K / V (and dO below) are read by the attention kernels only: the projections store them pre-split (hi/lo bf16 chunks), so
+    # the K/V tiles every query block stages -- and Q / dO in the backward -- need no fp32 -> hi/lo conversion there
+    ps = config.ATTN_PRESPLIT
     if mem is None:
         qkv = _empty(Nq, 3 * E, like=x.v)
-        ops.linear_fwd(x.v, W, bias, qkv)
+        ops.linear_fwd(x.v, W, bias, qkv, out_split=ps)
         Q, K, V = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
     else:
         q = _empty(Nq, E, like=x.v)
         kv = _empty(Nk, 2 * E, like=x.v)
-        ops.linear_fwd(x.v, W[:E], bias[:E], q)
-        ops.linear_fwd(mem.v, W[E:], bias[E:], kv)
+        ops.linear_fwd(x.v, W[:E], bias[:E], q, out_split=ps)
+        ops.linear_fwd(mem.v, W[E:], bias[E:], kv, out_split=ps)
         Q, K, V = q, kv[:, :E], kv[:, E:]
     O = _empty(Nq, E, like=x.v)
     LSE = _empty(B, H, Tq, like=x.v)
-    ops.attn_fwd(Q, K, V, O, LSE, lens_k, B, H, Tq, Tk, causal, drop_p=p, seed=cx.seed, stream_id=s_attn)
+    ops.attn_fwd(Q, K, V, O, LSE, lens_k, B, H, Tq, Tk, causal, drop_p=p, seed=cx.seed, stream_id=s_attn, qkv_split=ps)
     z = _empty(Nq, E, like=x.v)
     ops.linear_fwd(O, Wo, bo, z, drop_p=p, seed=cx.seed, stream_id=s_out, R=x.v)          # z = x + drop(O Wo^T + bo)
     y, mean, rstd = _layernorm(cx, tape, z, pre_norm, None)
@@ -107,13 +110,13 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
             if gWo is not None:
                 ops.linear_wgrad(da, O, gWo, db=st.g(pre_attn + "out_proj.bias"))
             dO = _empty(Nq, E, like=z)
-            ops.linear_dgrad(da, Wo, dO)
+            ops.linear_dgrad(da, Wo, dO, out_split=ps)
             delta = _empty(B, H, Tq, like=z)
             gW, gb = st.g(pre_attn + "in_proj_weight"), st.g(pre_attn + "in_proj_bias")
             if mem is None:
                 dqkv = _empty(Nq, 3 * E, like=z)
                 ops.attn_bwd(Q, K, V, O, dO, LSE, delta, dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:], lens_k, B, H, Tq, Tk, causal,
-                             drop_p=p, seed=seed, stream_id=s_attn)
+                             drop_p=p, seed=seed, stream_id=s_attn, qkv_split=ps)
                 if gW is not None:
                     ops.linear_wgrad(dqkv, x.v, gW, db=gb)
                 dx = _empty(Nq, E, like=z)
@@ -122,7 +125,7 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
                 dq = _empty(Nq, E, like=z)
                 dkv = _empty(Nk, 2 * E, like=z)
                 ops.attn_bwd(Q, K, V, O, dO, LSE, delta, dq, dkv[:, :E], dkv[:, E:], lens_k, B, H, Tq, Tk, causal,
-                             drop_p=p, seed=seed, stream_id=s_attn)
+                             drop_p=p, seed=seed, stream_id=s_attn, qkv_split=ps)
                 if gW is not None:
                     ops.linear_wgrad(dq, x.v, gW[:E], db=gb[:E])
                     ops.linear_wgrad(dkv, mem.v, gW[E:], db=gb[E:])

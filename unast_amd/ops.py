@@ -67,8 +67,8 @@ def _transposed_weight(W):
 
 def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bias=None, R=None, ldr=0, G=None,
          ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False, rowsum_a=None, kb_valid=0, tile_wn=0,
-         b_ptr=None):
-    """b_ptr: B given as a raw device pointer to a PRE-SPLIT operand (a transposed weight copy); `B` is then only a shape/dtype witness."""
+         b_ptr=None, out_split=False):
+    """out_split: C is written in the pre-split operand format (for the attention kernels).  b_ptr: B given as a raw device pointer to a PRE-SPLIT operand (a transposed weight copy); `B` is then only a shape/dtype witness."""
     if A.dtype is not _F32 or B.dtype is not _F32 or C.dtype is not _F32 or not C.is_cuda:       # (epilogue operands are produced by this package)
         for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (R, "R"), (G, "G")):
             _f32(t, n)
@@ -86,7 +86,7 @@ def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bia
     check(lib().unast_gemm(a_mode, b_mode, nsplit or config.NSPLIT, _p(A), lda, bp, ldb, _p(C), ldc, M, N, K, kb_valid,
                            conv[0], conv[1], conv[2], conv[3], _p(bias), _p(R), ldr, _p(G), ldg, gate_scale,
                            alpha, beta, act, drop_p, seed & 0xFFFFFFFF, stream_id, splitk, _p(ws), ws_n, _p(rowsum_a), tile_wn, presplit,
-                           _stream()), "unast_gemm")
+                           int(out_split), _stream()), "unast_gemm")
 
 
 import os as _os
@@ -107,16 +107,16 @@ def _splitk_for(M, N, K):
     return max(1, min(want, ksteps // SPLITK_MIN_KSTEPS))
 
 
-def linear_fwd(x2d, W, bias, out, act=0, drop_p=0.0, seed=0, stream_id=0, R=None):
+def linear_fwd(x2d, W, bias, out, act=0, drop_p=0.0, seed=0, stream_id=0, R=None, out_split=False):
     """out[M,N] = epi(x2d[M,K] @ W[N,K]^T + bias)."""
     M, K = x2d.shape
     N = W.shape[0]
     gemm(OP_KC, OP_KC, x2d, x2d.stride(0), W, W.stride(0), out, out.stride(0), M, N, K, bias=bias, act=act,
-         drop_p=drop_p, seed=seed, stream_id=stream_id, R=R, ldr=(R.stride(0) if R is not None else 0))
+         drop_p=drop_p, seed=seed, stream_id=stream_id, R=R, ldr=(R.stride(0) if R is not None else 0), out_split=out_split)
     return out
 
 
-def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0):
+def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0, out_split=False):
     """dx[M,K] = (dy2d[M,N] @ W[N,K]) gated by G>0, + R."""
     M, N = dy2d.shape
     K = W.shape[1]
@@ -127,11 +127,11 @@ def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0):
     if wt is not None:             # dX = dY (W^T)^T with W^T stored pre-split and K-contiguous: the forward GEMM's operand form
         gemm(OP_KC, OP_KC, dy2d, dy2d.stride(0), W, wt[1], dx, dx.stride(0), M, K, Np, R=R,
              ldr=(R.stride(0) if R is not None else 0), G=G, ldg=(G.stride(0) if G is not None else 0),
-             gate_scale=gate_scale, beta=beta, b_ptr=wt[0])
+             gate_scale=gate_scale, beta=beta, b_ptr=wt[0], out_split=out_split)
         return dx
     gemm(OP_KC, OP_RC, dy2d, dy2d.stride(0), W, W.stride(0), dx, dx.stride(0), M, K, Np, R=R,
          ldr=(R.stride(0) if R is not None else 0), G=G, ldg=(G.stride(0) if G is not None else 0),
-         gate_scale=gate_scale, beta=beta, kb_valid=N)
+         gate_scale=gate_scale, beta=beta, kb_valid=N, out_split=out_split)
     return dx
 
 
@@ -319,18 +319,18 @@ def conv_wgrad(dy3d, x3d, dWp, pad_left, db=None):
 
 
 # ---- attention ---------------------------------------------------------------------------------------------
-def attn_fwd(Q, K, V, O, LSE, lens_k, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, stream_id=0, nsplit=None):
+def attn_fwd(Q, K, V, O, LSE, lens_k, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, stream_id=0, nsplit=None, qkv_split=False):
     """Q/K/V/O are 2-D views [B*T, >=H*64] (column slices of projection outputs are fine)."""
     check(lib().unast_attn_fwd(nsplit or config.NSPLIT, _p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0),
                                _p(LSE), _p(lens_k), B, H, Tq, Tk, 64, int(causal), 0.125, drop_p, seed & 0xFFFFFFFF, stream_id,
-                               _stream()), "unast_attn_fwd")
+                               int(qkv_split), _stream()), "unast_attn_fwd")
 
 
-def attn_bwd(Q, K, V, O, dO, LSE, delta_ws, dQ, dK, dV, lens_k, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, stream_id=0, nsplit=None):
+def attn_bwd(Q, K, V, O, dO, LSE, delta_ws, dQ, dK, dV, lens_k, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, stream_id=0, nsplit=None, qkv_split=False):
     check(lib().unast_attn_bwd(nsplit or config.NSPLIT, _p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0),
                                _p(dO), dO.stride(0), _p(LSE), _p(delta_ws), _p(dQ), dQ.stride(0), _p(dK), dK.stride(0), _p(dV),
                                dV.stride(0), _p(lens_k), B, H, Tq, Tk, 64, int(causal), 0.125, drop_p, seed & 0xFFFFFFFF, stream_id,
-                               int(config.ATTN_FUSED_BWD), _stream()), "unast_attn_bwd")
+                               int(config.ATTN_FUSED_BWD), int(qkv_split), _stream()), "unast_attn_bwd")
 
 
 # ---- normalisation -----------------------------------------------------------------------------------------
