@@ -18,7 +18,13 @@ for (B, Tq, Tk, causal) in [(32, 800, 800, 0), (32, 800, 800, 1), (32, 180, 180,
     O = torch.empty(B * Tq, E, device=D); LSE = torch.empty(B, H, Tq, device=D); lens = torch.full((B,), Tk, dtype=torch.int32, device=D)
     dO = torch.randn(B * Tq, E, device=D); ws = torch.empty(B, H, Tq, device=D); dQ = torch.empty(B * Tq, E, device=D); dKV = torch.empty(B * Tk, 2 * E, device=D)
     from unast_amd import config
+    qkv_s, kv_s, dO_s = torch.empty_like(qkv), torch.empty_like(kv), torch.empty_like(dO)
+    ops.split_f32(qkv.view(-1), qkv_s.view(-1)); ops.split_f32(kv.view(-1), kv_s.view(-1)); ops.split_f32(dO.view(-1), dO_s.view(-1))
+    if Tk == Tq:
+        kv_s = qkv_s
     for p in (0.0, 0.1):
+        fs = timeit(lambda: ops.attn_fwd(qkv_s[:, :E], kv_s[:, E:2*E], kv_s[:, 2*E:], O, LSE, lens, B, H, Tq, Tk, causal, drop_p=p, seed=1, stream_id=1, qkv_split=True))
+        bs = timeit(lambda: ops.attn_bwd(qkv_s[:, :E], kv_s[:, E:2*E], kv_s[:, 2*E:], O, dO_s, LSE, ws, dQ, dKV[:, :E], dKV[:, E:], lens, B, H, Tq, Tk, causal, drop_p=p, seed=1, stream_id=1, qkv_split=True))
         config.ATTN_FUSED_BWD = False
         b0 = timeit(lambda: ops.attn_bwd(qkv[:, :E], kv[:, E:2*E], kv[:, 2*E:], O, dO, LSE, ws, dQ, dKV[:, :E], dKV[:, E:], lens, B, H, Tq, Tk, causal, drop_p=p, seed=1, stream_id=1))
         config.ATTN_FUSED_BWD = True
@@ -26,4 +32,4 @@ for (B, Tq, Tk, causal) in [(32, 800, 800, 0), (32, 800, 800, 1), (32, 180, 180,
         b = timeit(lambda: ops.attn_bwd(qkv[:, :E], kv[:, E:2*E], kv[:, 2*E:], O, dO, LSE, ws, dQ, dKV[:, :E], dKV[:, E:], lens, B, H, Tq, Tk, causal, drop_p=p, seed=1, stream_id=1))
         pairs = Tq * (Tq + 1) / 2 if causal else Tq * Tk
         fl = 4.0 * B * H * pairs * 64
-        print((B, Tq, Tk, causal), "p=%.1f fwd %.0f us (%.0f TF)  bwd fused %.0f us (%.0f TF)  bwd two-kernel %.0f us" % (p, f, fl / f / 1e6, b, 2.5 * fl / b / 1e6, b0), flush=True)
+        print((B, Tq, Tk, causal), "p=%.1f fwd %.0f us (%.0f TF; pre-split operands %.0f us)  bwd fused %.0f us (%.0f TF; pre-split %.0f us)  bwd two-kernel %.0f us" % (p, f, fl / f / 1e6, fs, b, 2.5 * fl / b / 1e6, bs, b0), flush=True)
