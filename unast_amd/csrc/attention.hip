@@ -13,6 +13,7 @@
 //   dK/dV kernel: S[q,key] = Q.K^T puts the KEY on the lane; P and dS accumulators are then the B operands of
 //   dV^T = dO^T.P and dK^T = Q^T.dS, with dO^T / Q^T read transposed from the same [q][d] LDS images that feed S, dP.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 #define HD 64
@@ -105,20 +106,20 @@ __device__ __forceinline__ f32x4 mma3(const bf16x8_t& ah, const bf16x8_t& al, co
 }
 
 // global [rows x 64] fp32 tile -> registers (NF float4 per thread); rows >= rows_valid read as zero
-template <int NROWS>
-__device__ __forceinline__ void tile_load(const float* __restrict__ src, int ld, int rows_valid, float4 (&r)[NROWS / 16], int t) {
+template <int NROWS, int NT = 256>
+__device__ __forceinline__ void tile_load(const float* __restrict__ src, int ld, int rows_valid, float4 (&r)[NROWS * 16 / NT], int t) {
 #pragma unroll
-    for (int i = 0; i < NROWS / 16; ++i) {
-        const int idx = t + 256 * i;
+    for (int i = 0; i < NROWS * 16 / NT; ++i) {
+        const int idx = t + NT * i;
         const int row = idx >> 4, dq = (idx & 15) * 4;
         r[i] = (row < rows_valid) ? *reinterpret_cast<const float4*>(src + (size_t)row * ld + dq) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
-template <int NROWS, int NSPLIT>
-__device__ __forceinline__ void tile_store(const float4 (&r)[NROWS / 16], unsigned char* hi_img, unsigned char* lo_img, int t, bool split_in = false) {
+template <int NROWS, int NSPLIT, int NT = 256>
+__device__ __forceinline__ void tile_store(const float4 (&r)[NROWS * 16 / NT], unsigned char* hi_img, unsigned char* lo_img, int t, bool split_in = false) {
 #pragma unroll
-    for (int i = 0; i < NROWS / 16; ++i) {
-        const int idx = t + 256 * i;
+    for (int i = 0; i < NROWS * 16 / NT; ++i) {
+        const int idx = t + NT * i;
         const int row = idx >> 4, dq = (idx & 15) * 4;
         u32x2 hi, lo;
         if (split_in) {     // already [hi x4 | lo x4]
@@ -148,9 +149,13 @@ static inline unsigned xcd_grid(int nx, int nbh) { return (unsigned)(((nbh + 7) 
 // MODE 0: forward (O, LSE).  MODE 1: dQ (recomputes P from LSE; dQ = scale * dS.K).
 // 1-D grid of ceil(Tq/128) * B*H workgroups (XCD-remapped), 256 threads; wave w owns queries [128*bx + 32w, +32).
 // ------------------------------------------------------------------------------------------------------------
-template <int NSPLIT, int MODE>
-__global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
+// QS = 16-query sub-tiles per wave: 2 -> 4 waves x 32 queries (256 VGPRs, 2 waves/SIMD); 1 -> 8 waves x 16 queries, whose
+// halved per-wave state (Q fragments, S and O accumulators, prefetch registers) fits 128 VGPRs = 4 waves/SIMD: the same MFMA
+// and vector work per workgroup, twice the waves to hide LDS / exp / barrier latencies behind.
+template <int NSPLIT, int MODE, int QS>
+__global__ __launch_bounds__(128 * (4 / QS), (QS == 1 ? 4 : 2)) void attn_q_kernel(const AttnParams p) {
     constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
+    constexpr int NT = 128 * (4 / QS);                        // 512 threads (QS = 1) or 256 (QS = 2): 128 queries per workgroup either way
     constexpr int IMG = 64 * ALD * 2;                         // one 64-row image
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PARTS * IMG];
     unsigned char* sK[2] = {smem, smem + (PARTS - 1) * IMG};
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
     if (p.causal) bx = (p.Tq + 127) / 128 - 1 - bx;                     // late query blocks see the most keys: dispatch them first
     const int h = bh % p.H, b = bh / p.H;
     const int qblk = bx * 128;
-    const int q0 = qblk + wave * 32;
+    const int q0 = qblk + wave * 16 * QS;
     const int klen = p.lens_k ? min(p.Tk, p.lens_k[b]) : p.Tk;
     int kmax = klen;
     if (p.causal) kmax = min(kmax, qblk + 128);
@@ -178,10 +183,12 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
     // there the factor rides in the exponent's fma (ssc) instead -- the same instruction count either way.
     const bool split_in = p.qkv_split != 0;
     const float ssc = split_in ? sc : 1.f;
-    bf16x8_t qf[2][2][PARTS], dof[2][2][PARTS];
-    float lse2[2] = {0.f, 0.f}, delta[2] = {0.f, 0.f};
+    bf16x8_t qf[QS][2][PARTS], dof[QS][2][PARTS];
+    float lse2[QS], delta[QS];
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < QS; ++qs) { lse2[qs] = 0.f; delta[qs] = 0.f; }
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
         const int q = q0 + 16 * qs + l15;
         const bool ok = q < p.Tq;
 #pragma unroll
@@ -202,39 +209,43 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
         }
     }
 
-    uint32_t rkeys[2] = {0u, 0u};
+    uint32_t rkeys[QS];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) rkeys[qs] = 0u;
     if (p.drop_thresh) {
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs)
+        for (int qs = 0; qs < QS; ++qs)
             rkeys[qs] = rng_row_key(p.seed, p.stream, (uint32_t)(((size_t)b * p.H + h) * p.Tq + q0 + 16 * qs + l15));
     }
-    float m[2] = {NEG_BIG, NEG_BIG}, lsum[2] = {0.f, 0.f};
-    f32x4 o[4][2];
+    float m[QS], lsum[QS];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) { m[qs] = NEG_BIG; lsum[qs] = 0.f; }
+    f32x4 o[4][QS];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) o[dt][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int qs = 0; qs < QS; ++qs) o[dt][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 rk[4], rv[4];
+    float4 rk[1024 / NT], rv[1024 / NT];
     if (nkt > 0) {
-        tile_load<64>(Kb, p.ldk, min(64, p.Tk), rk, t);
-        tile_load<64>(Vb, p.ldv, min(64, p.Tk), rv, t);
+        tile_load<64, NT>(Kb, p.ldk, min(64, p.Tk), rk, t);
+        tile_load<64, NT>(Vb, p.ldv, min(64, p.Tk), rv, t);
     }
     for (int kt = 0; kt < nkt; ++kt) {
-        tile_store<64, NSPLIT>(rk, sK[0], sK[PARTS - 1], t, split_in);
-        tile_store<64, NSPLIT>(rv, sV[0], sV[PARTS - 1], t, split_in);
+        tile_store<64, NSPLIT, NT>(rk, sK[0], sK[PARTS - 1], t, split_in);
+        tile_store<64, NSPLIT, NT>(rv, sV[0], sV[PARTS - 1], t, split_in);
         __syncthreads();
         if (kt + 1 < nkt) {
             const int kr = (kt + 1) * 64;
-            tile_load<64>(Kb + (size_t)kr * p.ldk, p.ldk, min(64, p.Tk - kr), rk, t);
-            tile_load<64>(Vb + (size_t)kr * p.ldv, p.ldv, min(64, p.Tk - kr), rv, t);
+            tile_load<64, NT>(Kb + (size_t)kr * p.ldk, p.ldk, min(64, p.Tk - kr), rk, t);
+            tile_load<64, NT>(Vb + (size_t)kr * p.ldv, p.ldv, min(64, p.Tk - kr), rv, t);
         }
         // ---- S^T[key,q] (and dP^T in dQ mode) -----------------------------------------------------------
-        f32x4 s[4][2], dp[4][2];
+        f32x4 s[4][QS], dp[4][QS];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs) { s[ks][qs] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[ks][qs] = s[ks][qs]; }
+            for (int qs = 0; qs < QS; ++qs) { s[ks][qs] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[ks][qs] = s[ks][qs]; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -242,22 +253,22 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
                 const bf16x8_t kh = row_frag(sK[0], 16 * ks, kst, l15, g);
                 const bf16x8_t kl = (PARTS == 2) ? row_frag(sK[PARTS - 1], 16 * ks, kst, l15, g) : kh;
 #pragma unroll
-                for (int qs = 0; qs < 2; ++qs) s[ks][qs] = mma3<NSPLIT>(kh, kl, qf[qs][kst][0], qf[qs][kst][PARTS - 1], s[ks][qs]);
+                for (int qs = 0; qs < QS; ++qs) s[ks][qs] = mma3<NSPLIT>(kh, kl, qf[qs][kst][0], qf[qs][kst][PARTS - 1], s[ks][qs]);
                 if (MODE == 1) {
                     const bf16x8_t vh = row_frag(sV[0], 16 * ks, kst, l15, g);
                     const bf16x8_t vl = (PARTS == 2) ? row_frag(sV[PARTS - 1], 16 * ks, kst, l15, g) : vh;
 #pragma unroll
-                    for (int qs = 0; qs < 2; ++qs) dp[ks][qs] = mma3<NSPLIT>(vh, vl, dof[qs][kst][0], dof[qs][kst][PARTS - 1], dp[ks][qs]);
+                    for (int qs = 0; qs < QS; ++qs) dp[ks][qs] = mma3<NSPLIT>(vh, vl, dof[qs][kst][0], dof[qs][kst][PARTS - 1], dp[ks][qs]);
                 }
             }
         // ---- softmax (fwd: online; dQ: from saved LSE) ---------------------------------------------------
         // Interior tiles (every key < klen and, if causal, below the diagonal for all 32 queries of this wave) take a
         // path without per-element mask tests; the condition is wave-uniform.
-        const bool interior = (kt * 64 + 64 <= klen) && (!p.causal || kt * 64 + 63 <= q0) && (MODE == 0 || q0 + 31 < p.Tq);
+        const bool interior = (kt * 64 + 64 <= klen) && (!p.causal || kt * 64 + 63 <= q0) && (MODE == 0 || q0 + 16 * QS - 1 < p.Tq);
         auto softmax_tile = [&](auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs) {
+            for (int qs = 0; qs < QS; ++qs) {
                 const int q = q0 + 16 * qs + l15;
                 const uint32_t rkey = rkeys[qs];
                 float mref;
@@ -328,9 +339,9 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
         unsigned char* const* sX = (MODE == 0) ? sV : sK;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            bf16x8_t pf[2][PARTS];
+            bf16x8_t pf[QS][PARTS];
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs) {
+            for (int qs = 0; qs < QS; ++qs) {
                 bf16x8_t hi, lo;
                 pack_acc<NSPLIT>(s[2 * u][qs], s[2 * u + 1][qs], hi, lo);
                 pf[qs][0] = hi;
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
                 const bf16x8_t xh = tr_frag(sX[0], 32 * u, 16 * dt, l15, g);
                 const bf16x8_t xl = (PARTS == 2) ? tr_frag(sX[PARTS - 1], 32 * u, 16 * dt, l15, g) : xh;
 #pragma unroll
-                for (int qs = 0; qs < 2; ++qs) o[dt][qs] = mma3<NSPLIT>(xh, xl, pf[qs][0], pf[qs][PARTS - 1], o[dt][qs]);
+                for (int qs = 0; qs < QS; ++qs) o[dt][qs] = mma3<NSPLIT>(xh, xl, pf[qs][0], pf[qs][PARTS - 1], o[dt][qs]);
             }
         }
         __syncthreads();
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const AttnParams p) {
 
     // ---- epilogue: lane holds O^T[d = 16dt+4g+r][q = q0+16qs+l15] ------------------------------------------
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < QS; ++qs) {
         const int q = q0 + 16 * qs + l15;
         if (q >= p.Tq) continue;
         const float f = (MODE == 0) ? (lsum[qs] > 0.f ? 1.f / lsum[qs] : 0.f) : p.scale;
@@ -633,9 +644,12 @@ extern "C" int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* 
     UNAST_REQUIRE(O && LSE && al16(O) && (ldo & 3) == 0, "unast_attn_fwd: bad output");
     UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_attn_fwd: nsplit must be 1 or 3");
     p.O = O; p.ldo = ldo; p.LSE = LSE;
+    // 8 waves x 16 queries (128 VGPRs, 4 waves/SIMD) instead of 4 x 32 (248 VGPRs, 2 waves/SIMD): measured equal on MI355X (109 vs 108 us at
+    // 800x800, every config-3 shape within 3 %) -- occupancy is not what bounds this kernel -- so the 4-wave form stays the default.
+    static const bool q16 = [] { const char* e = getenv("UNAST_ATTN_FWD_Q16"); return e && e[0] == '1'; }();
     dim3 grid(xcd_grid((Tq + 127) / 128, B * H));
-    if (nsplit == 3) hipLaunchKernelGGL((attn_q_kernel<3, 0>), grid, dim3(256), 0, stream, p);
-    else             hipLaunchKernelGGL((attn_q_kernel<1, 0>), grid, dim3(256), 0, stream, p);
+    if (nsplit == 3) if (q16) hipLaunchKernelGGL((attn_q_kernel<3, 0, 1>), grid, dim3(512), 0, stream, p); else hipLaunchKernelGGL((attn_q_kernel<3, 0, 2>), grid, dim3(256), 0, stream, p);
+    else             if (q16) hipLaunchKernelGGL((attn_q_kernel<1, 0, 1>), grid, dim3(512), 0, stream, p); else hipLaunchKernelGGL((attn_q_kernel<1, 0, 2>), grid, dim3(256), 0, stream, p);
     return unast_check_launch("unast_attn_fwd");
 }
 
@@ -659,10 +673,10 @@ extern "C" int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* 
         if (nsplit == 3) hipLaunchKernelGGL((attn_dkv_kernel<3, 1>), gk, dim3(256), 0, stream, p);
         else             hipLaunchKernelGGL((attn_dkv_kernel<1, 1>), gk, dim3(256), 0, stream, p);
     } else if (nsplit == 3) {
-        hipLaunchKernelGGL((attn_q_kernel<3, 1>), gq, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_q_kernel<3, 1, 2>), gq, dim3(256), 0, stream, p);
         hipLaunchKernelGGL((attn_dkv_kernel<3, 0>), gk, dim3(256), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((attn_q_kernel<1, 1>), gq, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_q_kernel<1, 1, 2>), gq, dim3(256), 0, stream, p);
         hipLaunchKernelGGL((attn_dkv_kernel<1, 0>), gk, dim3(256), 0, stream, p);
     }
     return unast_check_launch("unast_attn_bwd");
