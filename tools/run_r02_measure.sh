@@ -11,6 +11,7 @@ timeout -k 10 300 python bench.py --no-cpu-baseline --launch graph > gpurun_out/
 grep -o "\"ms_per_step\": [0-9.]*, \"higher" gpurun_out/r2_final_*.json
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_r02b -- python3 /root/repo/bench.py --launch eager --no-cpu-baseline --steps 10 --warmup 3 > /root/repo/gpurun_out/prof_r02b.log 2>&1
+UNAST_SIDE_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_r02c -- python3 /root/repo/bench.py --launch eager --no-cpu-baseline --steps 6 --warmup 2 > /root/repo/gpurun_out/prof_r02c.log 2>&1
 cd /root/repo
 bash tools/pmc_hbm_traffic.sh r02_pmc_hbm_traffic > gpurun_out/r2_pmc_traffic.log 2>&1; tail -16 gpurun_out/r2_pmc_traffic.log
 bash tools/pmc_attn.sh gpurun_out/pmc_attn_r02 > gpurun_out/r2_pmc_attn.log 2>&1; grep -n "avg launch\|MFMA busy\|SQ_VALU_MFMA_BUSY\|GRBM_GUI\|SQ_INSTS_VALU\|SQ_INSTS_MFMA" gpurun_out/r2_pmc_attn.log
