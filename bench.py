@@ -402,8 +402,8 @@ def main():
                 "attn_bwd": mfma_entry("attn_bwd", ATTN_BWD_KERNEL % {"n": config.NSPLIT}),
                 "note": "dominant family = GEMM.  achieved = algorithmic bytes (fp32 A + B + C and epilogue operands, each once; conv inputs once, not "
                         "per tap) / HIP-event time of these launches, taken on the launch stream in the isolated single-stream steps after the "
-                        "timed region (the timed region replays a captured HIP graph with four streams: no per-kernel host hooks there, and a "
-                        "launch would share the chip with the other streams' kernels); traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE per launch "
+                        "timed region (inside the timed region a launch shares the chip with the kernels of the other three streams, and a replayed "
+                        "capture has no per-kernel host hooks); traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE per launch "
                         "from profiles/ (separate rocprofv3 passes of this command), null if absent; mfma_view / attn_*: 2MNK FLOPs per "
                         "contraction, 4*B*H*Tq*Tk*64 per attention forward (x2.5 backward, causal at T(T+1)/2); each product costs %d bf16 MFMAs in "
                         "%s mode; sustained MFMA peak = tools/mfma_peak.cpp on this chip" % (config.NSPLIT, a.precision)}
