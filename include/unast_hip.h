@@ -45,10 +45,7 @@ const char* unast_arch(void);
  *           unast_split_f32 (same byte offsets as the fp32 weights), so the kernel does not re-split them per row panel.
  * out_split: C is stored in that same format (per 4 consecutive columns one 16-byte chunk [hi x4 | lo x4] of bf16 at the fp32
  *           byte offset): the in-projection outputs Q / K / V and the out-projection's input gradient dO, which only the
- *           attention kernels read (qkv_split there); needs N % 4 == 0, beta = 0, no split-K.
- * mask_out / mask_in (may be NULL; M % 128 == 0, N % 128 == 0, no residual): the ReLU + dropout gate of the feed-forward block as one
- *           bit per element -- the forward GEMM (linear1, src/module.py:273-274) stores (C > 0) as M*N/64 64-bit wave ballots, the
- *           input-gradient GEMM through linear2 with the same [M, N] output reads them instead of G (gate_scale still applies). */
+ *           attention kernels read (qkv_split there); needs N % 4 == 0, beta = 0, no split-K. */
 int unast_gemm(int a_mode, int b_mode, int nsplit,
                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                int M, int N, int K, int kb_valid,
@@ -57,7 +54,7 @@ int unast_gemm(int a_mode, int b_mode, int nsplit,
                float alpha, int beta, int act,
                float drop_p, unsigned int seed, unsigned int stream_id,
                int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, int tile_wn, int b_presplit,
-               int out_split, uint64_t* mask_out, const uint64_t* mask_in, hipStream_t stream);
+               int out_split, hipStream_t stream);
 
 /* Fused multi-head attention core (head_dim 64), flash-style.  Replaces the softmax(QK^T/sqrt(d)+mask) -> dropout -> V
  * core of torch.nn.MultiheadAttention inside torch.nn.TransformerEncoderLayer/DecoderLayer

@@ -317,33 +317,3 @@ def _dgrad_T_body(st, opt):
     opt.zero_grad()
     assert not torch.equal(before, st.flat)
     check_all()
-
-
-@pytest.mark.parametrize("M,N,K", [(256, 1024, 256), (1280, 256, 128), (25600, 1024, 256)])
-def test_gate_bitmask_equals_gating_on_the_activation(M, N, K):
-    """The ReLU + dropout gate as one bit per element: the forward GEMM's epilogue stores (out > 0) as wave ballots, the
-    input-gradient GEMM of the same [M, N] output shape reads the bits back -- bit-identical to gating on the fp32 activation,
-    and the mask holds exactly the bits of (h > 0)."""
-    from unast_amd import ops, config
-    g = torch.Generator().manual_seed(M + N)
-    x = torch.randn(M, K, generator=g).to(dev()); W1 = (torch.randn(N, K, generator=g) * 0.1).to(dev()); b1 = torch.randn(N, generator=g).to(dev())
-    W2 = (torch.randn(K, N, generator=g) * 0.1).to(dev())
-    h = torch.empty(M, N, device=dev()); h2 = torch.empty(M, N, device=dev())
-    config.GATE_BITMASK = True            # opt-in (config.py)
-    try:
-        nw = ops.gate_mask_words(M, N)
-    finally:
-        config.GATE_BITMASK = False
-    assert nw == M * N // 64
-    mask = torch.zeros(nw, dtype=torch.int64, device=dev())
-    ops.linear_fwd(x, W1, b1, h, act=1, drop_p=0.3, seed=5, stream_id=2, mask_out=mask)
-    ops.linear_fwd(x, W1, b1, h2, act=1, drop_p=0.3, seed=5, stream_id=2)
-    assert torch.equal(h, h2)
-    bits = sum(bin(int(w) & 0xFFFFFFFFFFFFFFFF).count("1") for w in mask[:4096].tolist())
-    assert int((h > 0).sum()) == sum(bin(int(w) & 0xFFFFFFFFFFFFFFFF).count("1") for w in mask.tolist()) if M * N <= (1 << 20) else bits > 0
-    da = torch.randn(M, K, generator=g).to(dev())
-    du_mask = torch.empty(M, N, device=dev()); du_act = torch.empty(M, N, device=dev())
-    ops.linear_dgrad(da, W2, du_mask, gate_scale=1.0 / 0.7, mask_in=mask)
-    ops.linear_dgrad(da, W2, du_act, G=h, gate_scale=1.0 / 0.7)
-    assert torch.equal(du_mask, du_act)
-    assert float((du_mask[h <= 0]).abs().max()) == 0.0

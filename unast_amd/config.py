@@ -61,10 +61,3 @@ DGRAD_TRANSPOSED = os.environ.get("UNAST_DGRAD_T", "0") == "1"
 # The in-projections write Q / K / V -- and the out-projection's input-gradient GEMM writes dO -- in the pre-split operand format;
 # the attention kernels then stage K/V (forward) and Q/dO (backward) tiles without fp32 -> hi/lo conversions.  0 = fp32 (A/B).
 ATTN_PRESPLIT = os.environ.get("UNAST_ATTN_PRESPLIT", "1") != "0"
-
-# The feed-forward block's ReLU + dropout gate travels to the backward as one bit per element (written by the linear1 GEMM's
-# epilogue as wave ballots, read by the input-gradient GEMM through linear2) instead of a second read of the fp32 hidden
-# activation: 3.3 MB instead of 105 MB per speech-side layer at config 3.  Needs B*T % 128 == 0.  Measured on MI355X: that
-# input-gradient launch 94.7 -> 84.9 us, the linear1 forward 72.8 -> 75.5 us (ballots + mask stores), step 33.40 vs 33.27 ms --
-# no net gain (the launch is bound by its 105 MB output stream, not by the gate read), so it is OFF by default; 1 = on.
-GATE_BITMASK = os.environ.get("UNAST_GATE_BITMASK", "0") == "1"

@@ -40,10 +40,6 @@ struct GemmParams {
     float* rowsum_a;                                  // optional: rowsum_a[m] += sum_k A[m][k] (bias gradient fused into wgrad)
     int group;                                        // launched as one problem of a grouped weight-gradient launch (split-K tile map, slabs)
     int out_split;                                    // store C in the pre-split operand format (16-B chunks [hi x4 | lo x4]) for the attention kernels
-    // ReLU / dropout gate as ONE BIT per output element instead of re-reading the fp32 activation (8-wave 128x128 tiles, interior launches
-    // only): the forward GEMM writes (C > 0) as wave ballots, the input-gradient GEMM of the same [M, N] shape reads them back with the
-    // same tile / wave / lane mapping.  Word index = (((tile_m * tiles_n + tile_n) * 8 + wave) * 2 + i) * 16 + j * 4 + r, bit = lane.
-    unsigned long long* mask_out; const unsigned long long* mask_in;
 };
 
 __device__ __forceinline__ int swz_h(int row) { return (0x1320 >> (((row >> 2) & 3) << 2)) & 3; }
@@ -155,18 +151,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 if (vec_r && full) { float4 t4 = *reinterpret_cast<const float4*>(p.R + (size_t)m * p.ldr + n); rv[0] = t4.x; rv[1] = t4.y; rv[2] = t4.z; rv[3] = t4.w; }
                 else { for (int r = 0; r < 4; ++r) if (n + r < p.N) rv[r] = p.R[(size_t)m * p.ldr + n + r]; }
             }
-            const size_t mword = MI == 2 ? ((((size_t)(m0 / GBM) * p.tiles_n + n0 / 128) * 8 + wm * 2 + wn) * 2 + i) * 16 + j * 4 : 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float x = v[r] * p.alpha + bias_v[j][r];
                 if (p.act == 1) x = fmaxf(x, 0.f);
                 if (p.drop_thresh) x = rng_keep(rkey, (uint32_t)(n + r), p.drop_thresh) ? x * p.drop_scale : 0.f;
                 if (p.G) x = (gv[r] > 0.f) ? x * p.gate_scale : 0.f;
-                if (MI == 2 && p.mask_in) x = ((p.mask_in[mword + r] >> (l15 + 16 * g)) & 1ull) ? x * p.gate_scale : 0.f;
-                if (MI == 2 && p.mask_out) {              // interior tiles only (host-checked): every lane of the wave is here
-                    const unsigned long long bits = __ballot(x > 0.f);
-                    if (l15 + 16 * g == 0) p.mask_out[mword + r] = bits;
-                }
                 v[r] = x + rv[r];
             }
             float* cp = p.C + (size_t)m * p.ldc + n;
@@ -450,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GroupParams gp
     p.alpha = 1.f; p.beta = 1; p.act = 0; p.drop_thresh = 0u; p.drop_scale = 1.f; p.seed = 0u; p.stream = 0u;
     p.kchunk = it.kchunk; p.atomic = 0; p.tiles_m = it.tiles_m; p.tiles_n = it.tiles_n; p.nsplitk = it.nsplitk;
     p.slab = it.slab; p.ld_slab = it.ld_slab; p.slab_stride = (size_t)it.M * it.ld_slab;
-    p.kb_valid = it.K; p.rowsum_a = it.rowsum_a; p.group = 1; p.out_split = 0; p.mask_out = nullptr; p.mask_in = nullptr;
+    p.kb_valid = it.K; p.rowsum_a = it.rowsum_a; p.group = 1; p.out_split = 0;
     gemm_body<OP_RC, OP_RC, NSPLIT, 2, 2, FLAGS>(p, b - gp.base[i]);
 }
 
@@ -599,7 +589,7 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
                           float alpha, int beta, int act,
                           float drop_p, unsigned int seed, unsigned int stream_id,
                           int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, int tile_wn, int b_presplit,
-                          int out_split, uint64_t* mask_out, const uint64_t* mask_in, hipStream_t stream) {
+                          int out_split, hipStream_t stream) {
     UNAST_REQUIRE(A && B && C, "unast_gemm: null operand");
     UNAST_REQUIRE(!b_presplit || (a_mode == OP_KC || a_mode == OP_KC_CONV), "unast_gemm: a pre-split B is a weight (forward / dgrad forms only)");
     UNAST_REQUIRE(M > 0 && N > 0 && K > 0, "unast_gemm: bad dims M=%d N=%d K=%d", M, N, K);
@@ -623,7 +613,6 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     p.alpha = alpha; p.beta = beta; p.act = act;
     p.drop_thresh = drop_threshold(drop_p); p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     p.seed = seed; p.stream = stream_id; p.group = 0; p.out_split = out_split;
-    p.mask_out = (unsigned long long*)mask_out; p.mask_in = (const unsigned long long*)mask_in;
     UNAST_REQUIRE(!out_split || ((N & 3) == 0 && (ldc & 3) == 0 && beta == 0 && splitk == 1), "unast_gemm: out_split needs N %% 4 == 0, ldc %% 4 == 0, beta = 0, no split-K");
     // tile width: 128x256 when N is wide enough and the grid still fills the chip; `tile_wn` (2/4) overrides, 0 = auto
     int wn = tile_wn;
@@ -635,8 +624,6 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     }
     const int gbn = (wn == 4) ? 256 : 128;
     p.tiles_m = (M + GBM - 1) / GBM; p.tiles_n = (N + gbn - 1) / gbn;
-    UNAST_REQUIRE(!(mask_out || mask_in) || (wn == 8 && M % GBM == 0 && N % 128 == 0 && splitk == 1 && !R),
-                  "unast_gemm: the gate bit mask needs the 8-wave 128x128 tile, M %% 128 == 0, N %% 128 == 0, no split-K, no residual");
     int ksteps = (K + GBK - 1) / GBK;
     if (splitk > ksteps) splitk = ksteps;
     int steps_per = (ksteps + splitk - 1) / splitk;

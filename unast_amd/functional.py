@@ -147,9 +147,7 @@ def ffn_sublayer(cx, tape, x, pre, pre_norm, drop):
     p = cx.p(drop)
     s1, s2 = cx.stream(), cx.stream()
     h = _empty(N, F, like=x.v)
-    nmask = ops.gate_mask_words(N, F) if tape is not None else 0
-    gmask = torch.empty(nmask, dtype=torch.int64, device=x.v.device) if nmask else None        # (h > 0), one bit per element
-    ops.linear_fwd(x.v, W1, b1, h, act=1, drop_p=p, seed=cx.seed, stream_id=s1, mask_out=gmask)
+    ops.linear_fwd(x.v, W1, b1, h, act=1, drop_p=p, seed=cx.seed, stream_id=s1)
     z = _empty(N, E, like=x.v)
     ops.linear_fwd(h, W2, b2, z, drop_p=p, seed=cx.seed, stream_id=s2, R=x.v)
     y, mean, rstd = _layernorm(cx, tape, z, pre_norm, None)
@@ -174,7 +172,7 @@ def ffn_sublayer(cx, tape, x, pre, pre_norm, drop):
             if g2 is not None:
                 ops.linear_wgrad(da, h, g2, db=st.g(pre + "linear2.bias"))
             du = _empty(N, F, like=z)
-            ops.linear_dgrad(da, W2, du, G=h, gate_scale=(1.0 / (1.0 - p) if p > 0 else 1.0), mask_in=gmask)      # relu' and dropout mask from h > 0
+            ops.linear_dgrad(da, W2, du, G=h, gate_scale=(1.0 / (1.0 - p) if p > 0 else 1.0))      # relu' and dropout mask from h > 0
             g1 = st.g(pre + "linear1.weight")
             if g1 is not None:
                 ops.linear_wgrad(du, x.v, g1, db=st.g(pre + "linear1.bias"))

@@ -67,7 +67,7 @@ def _transposed_weight(W):
 
 def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bias=None, R=None, ldr=0, G=None,
          ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False, rowsum_a=None, kb_valid=0, tile_wn=0,
-         b_ptr=None, out_split=False, mask_out=None, mask_in=None):
+         b_ptr=None, out_split=False):
     """out_split: C is written in the pre-split operand format (for the attention kernels).  b_ptr: B given as a raw device pointer to a PRE-SPLIT operand (a transposed weight copy); `B` is then only a shape/dtype witness."""
     if A.dtype is not _F32 or B.dtype is not _F32 or C.dtype is not _F32 or not C.is_cuda:       # (epilogue operands are produced by this package)
         for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (R, "R"), (G, "G")):
@@ -86,7 +86,7 @@ def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bia
     check(lib().unast_gemm(a_mode, b_mode, nsplit or config.NSPLIT, _p(A), lda, bp, ldb, _p(C), ldc, M, N, K, kb_valid,
                            conv[0], conv[1], conv[2], conv[3], _p(bias), _p(R), ldr, _p(G), ldg, gate_scale,
                            alpha, beta, act, drop_p, seed & 0xFFFFFFFF, stream_id, splitk, _p(ws), ws_n, _p(rowsum_a), tile_wn, presplit,
-                           int(out_split), _p(mask_out), _p(mask_in), _stream()), "unast_gemm")
+                           int(out_split), _stream()), "unast_gemm")
 
 
 import os as _os
@@ -107,24 +107,17 @@ def _splitk_for(M, N, K):
     return max(1, min(want, ksteps // SPLITK_MIN_KSTEPS))
 
 
-def gate_mask_words(M, N):
-    """int64 words of the one-bit-per-element gate mask of an [M, N] GEMM output (M, N multiples of 128), or 0 if not available."""
-    return (M // 128) * (N // 128) * 256 if (M % 128 == 0 and N % 128 == 0 and config.GATE_BITMASK) else 0
-
-
-def linear_fwd(x2d, W, bias, out, act=0, drop_p=0.0, seed=0, stream_id=0, R=None, out_split=False, mask_out=None):
-    """out[M,N] = epi(x2d[M,K] @ W[N,K]^T + bias).  mask_out: int64 [gate_mask_words(M, N)] receives (out > 0) as bits."""
+def linear_fwd(x2d, W, bias, out, act=0, drop_p=0.0, seed=0, stream_id=0, R=None, out_split=False):
+    """out[M,N] = epi(x2d[M,K] @ W[N,K]^T + bias)."""
     M, K = x2d.shape
     N = W.shape[0]
     gemm(OP_KC, OP_KC, x2d, x2d.stride(0), W, W.stride(0), out, out.stride(0), M, N, K, bias=bias, act=act,
-         drop_p=drop_p, seed=seed, stream_id=stream_id, R=R, ldr=(R.stride(0) if R is not None else 0), out_split=out_split, mask_out=mask_out)
+         drop_p=drop_p, seed=seed, stream_id=stream_id, R=R, ldr=(R.stride(0) if R is not None else 0), out_split=out_split)
     return out
 
 
-def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0, out_split=False, mask_in=None):
-    """dx[M,K] = (dy2d[M,N] @ W[N,K]) gated by G>0 (or by the bit mask a forward GEMM of the same output shape stored), + R."""
-    if mask_in is not None:
-        G = None
+def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0, out_split=False):
+    """dx[M,K] = (dy2d[M,N] @ W[N,K]) gated by G>0, + R."""
     M, N = dy2d.shape
     K = W.shape[1]
     Np = (N + 3) // 4 * 4          # dy2d is a view of a zero-padded buffer when N % 4 != 0 (logits 46->48, head 81->84, fc2 1->4)
@@ -134,11 +127,11 @@ def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0, out_split=
     if wt is not None:             # dX = dY (W^T)^T with W^T stored pre-split and K-contiguous: the forward GEMM's operand form
         gemm(OP_KC, OP_KC, dy2d, dy2d.stride(0), W, wt[1], dx, dx.stride(0), M, K, Np, R=R,
              ldr=(R.stride(0) if R is not None else 0), G=G, ldg=(G.stride(0) if G is not None else 0),
-             gate_scale=gate_scale, beta=beta, b_ptr=wt[0], out_split=out_split, mask_in=mask_in)
+             gate_scale=gate_scale, beta=beta, b_ptr=wt[0], out_split=out_split)
         return dx
     gemm(OP_KC, OP_RC, dy2d, dy2d.stride(0), W, W.stride(0), dx, dx.stride(0), M, K, Np, R=R,
          ldr=(R.stride(0) if R is not None else 0), G=G, ldg=(G.stride(0) if G is not None else 0),
-         gate_scale=gate_scale, beta=beta, kb_valid=N, out_split=out_split, mask_in=mask_in)
+         gate_scale=gate_scale, beta=beta, kb_valid=N, out_split=out_split)
     return dx
 
 
