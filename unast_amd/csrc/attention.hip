@@ -421,8 +421,10 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
 #pragma unroll
         for (int kst = 0; kst < 2; ++kst) {
             bf16x8_t hi, lo;
-            load_frag8<NSPLIT>(Kb + (size_t)key * p.ldk + 32 * kst + 8 * g, ok, split_in, 1.f, hi, lo);
-            kf[ks][kst][0] = hi; if (PARTS == 2) kf[ks][kst][PARTS - 1] = lo;
+            if (!FUSE_DQ) {      // (one-pass form: the K fragments are re-read from the workgroup's K image every iteration, see below)
+                load_frag8<NSPLIT>(Kb + (size_t)key * p.ldk + 32 * kst + 8 * g, ok, split_in, 1.f, hi, lo);
+                kf[ks][kst][0] = hi; if (PARTS == 2) kf[ks][kst][PARTS - 1] = lo;
+            }
             load_frag8<NSPLIT>(Vb + (size_t)key * p.ldv + 32 * kst + 8 * g, ok, split_in, 1.f, hi, lo);
             vf[ks][kst][0] = hi; if (PARTS == 2) vf[ks][kst][PARTS - 1] = lo;
         }
@@ -438,6 +440,15 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
     const int qt_begin = p.causal ? (kblk / 32) : 0;
     const int qt_end = block_live ? (p.Tq + 31) / 32 : qt_begin;
     float4 rq[2], rd[2];
+    // Softmax statistics of the query tile: lane L of every wave prefetches LSE (lanes 0-31) or Delta (lanes 32-63) of query
+    // L & 31 together with the Q / dO tile; the pointwise phase fetches its 2 x 4 rows with lane shuffles instead of eight
+    // dependent global loads in the middle of the iteration (the workgroup's LDS is full: 2 x 80 KB per CU).
+    float rl = 0.f, rl_cur = 0.f;
+    const float* const stat_src = (lane < 32) ? lseb : delb;
+    const float stat_mul = (lane < 32) ? LOG2E : 1.f;
+    auto stat_load = [&](int qtile) {          // a bare load: arithmetic on the result here would wait for it on the spot
+        rl = stat_src[min(qtile * 32 + (lane & 31), p.Tq - 1)];      // rows past Tq: any finite value, their probabilities are masked
+    };
     if (FUSE_DQ && qt_begin < qt_end) {          // the workgroup's 128 keys as the B operand of the dQ product (scale applied to dQ itself)
         float4 rk8[8];
         tile_load<128>(Kb + (size_t)kblk * p.ldk, p.ldk, min(128, p.Tk - kblk), rk8, t);
@@ -446,6 +457,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
     if (qt_begin < qt_end) {
         tile_load<32>(Qb + (size_t)qt_begin * 32 * p.ldq, p.ldq, min(32, p.Tq - qt_begin * 32), rq, t);
         tile_load<32>(dOb + (size_t)qt_begin * 32 * p.lddo, p.lddo, min(32, p.Tq - qt_begin * 32), rd, t);
+        stat_load(qt_begin);
     }
     // dQ of query tile `qtile` from the dS image's half `buf`: wave w owns head-dim columns [16w, 16w+16)
     auto dq_phase = [&](int qtile, int buf) {
@@ -473,12 +485,14 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
     for (int qt = qt_begin; qt < qt_end; ++qt) {
         tile_store<32, NSPLIT>(rq, sQ[0], sQ[PARTS - 1], t, split_in);
         tile_store<32, NSPLIT>(rd, sD[0], sD[PARTS - 1], t, split_in);
+        rl_cur = rl * stat_mul;
         __syncthreads();
         if (FUSE_DQ && qt > qt_begin) dq_phase(qt - 1, (qt - 1) & 1);
         if (qt + 1 < qt_end) {
             const int qr = (qt + 1) * 32;
             tile_load<32>(Qb + (size_t)qr * p.ldq, p.ldq, min(32, p.Tq - qr), rq, t);
             tile_load<32>(dOb + (size_t)qr * p.lddo, p.lddo, min(32, p.Tq - qr), rd, t);
+            stat_load(qt + 1);
         }
         // ---- S[q,key], dP[q,key] --------------------------------------------------------------------------
         f32x4 s[2][2], dp[2][2];
@@ -496,7 +510,15 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
                 const bf16x8_t dl = (PARTS == 2) ? row_frag(sD[PARTS - 1], 16 * qs, kst, l15, g) : dh;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    s[qs][ks] = mma3<NSPLIT>(qh, ql, kf[ks][kst][0], kf[ks][kst][PARTS - 1], s[qs][ks]);
+                    if (FUSE_DQ) {
+                        // The kernel sits at the 256-VGPR limit of 2 waves/SIMD; holding K in registers as well (32 VGPRs) made it
+                        // spill 18 of them inside this loop.  8 more ds_read_b128 per iteration instead: 281 -> 250 us at 800x800.
+                        const bf16x8_t kh = row_frag(sKs[0], wave * 32 + 16 * ks, kst, l15, g);
+                        const bf16x8_t kl = (PARTS == 2) ? row_frag(sKs[PARTS - 1], wave * 32 + 16 * ks, kst, l15, g) : kh;
+                        s[qs][ks] = mma3<NSPLIT>(qh, ql, kh, kl, s[qs][ks]);
+                    } else {
+                        s[qs][ks] = mma3<NSPLIT>(qh, ql, kf[ks][kst][0], kf[ks][kst][PARTS - 1], s[qs][ks]);
+                    }
                     dp[qs][ks] = mma3<NSPLIT>(dh, dl, vf[ks][kst][0], vf[ks][kst][PARTS - 1], dp[qs][ks]);
                 }
             }
@@ -511,8 +533,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
                 for (int r = 0; r < 4; ++r) {
                     const int q = qt * 32 + 16 * qs + 4 * g + r;
                     const bool qok = !MASKED || q < p.Tq;
-                    const float l2 = qok ? lseb[q] * LOG2E : 0.f;
-                    const float de = qok ? delb[q] : 0.f;
+                    const float l2 = __shfl(rl_cur, 16 * qs + 4 * g + r, 64);
+                    const float de = __shfl(rl_cur, 32 + 16 * qs + 4 * g + r, 64);
                     const uint32_t rkey = p.drop_thresh ? pcg_hash((uint32_t)(((size_t)b * p.H + h) * p.Tq + q) + rbase) : 0u;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
