@@ -62,17 +62,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // dz_drop = dz * dropout-mask(seed,stream,row,col) / (1-p): the gradient of the sub-layer output that was
 // dropped before the residual add in the forward pass.
 // ------------------------------------------------------------------------------------------------------------
+// NV = 256-column groups per row (C <= 256 * NV), RU = rows in flight per wave.  With one row in flight a wave has 2 KB of
+// loads outstanding and the 3 200 waves of a config-3 launch keep ~6 MB in flight -- the kernel then runs at ~3.2 TB/s, the
+// rate that latency allows; RU = 4 for the d = 256 model quadruples that.
+template <int NV, int RU>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dz,
                                                             float* __restrict__ dz_drop, float* __restrict__ part,
                                                             int rows, int C, int rows_per_block,
                                                             uint32_t drop_thresh, float drop_scale, uint32_t seed, uint32_t stream) {
-    __shared__ float red[2][4][LN_MAXV * 256];
+    __shared__ float red[2][4][NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 ag[LN_MAXV], ab[LN_MAXV], gm[LN_MAXV];
+    float4 ag[NV], ab[NV], gm[NV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         ag[i] = make_float4(0, 0, 0, 0);
         ab[i] = make_float4(0, 0, 0, 0);
         int c = (lane + 64 * i) * 4;
@@ -80,43 +84,62 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
-    for (int row = r0 + wave; row < r1; row += 4) {
-        const float mu = mean[row], rs = rstd[row];
-        float4 xh[LN_MAXV], g[LN_MAXV];
-        float s1 = 0.f, s2 = 0.f;
+    for (int row0 = r0 + wave; row0 < r1; row0 += 4 * RU) {
+        float4 dv[RU][NV], zv[RU][NV];
+        float mus[RU], rss[RU];
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            int c = (lane + 64 * i) * 4;
-            if (c < C) {
-                float4 d = *reinterpret_cast<const float4*>(dy + (size_t)row * C + c);
-                float4 zz = *reinterpret_cast<const float4*>(z + (size_t)row * C + c);
-                xh[i] = make_float4((zz.x - mu) * rs, (zz.y - mu) * rs, (zz.z - mu) * rs, (zz.w - mu) * rs);
-                g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
-                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
-                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
-                ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
-                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+        for (int u = 0; u < RU; ++u) {                     // all loads of the RU rows first (rows past the block re-read row0; not used)
+            const int row = (row0 + 4 * u < r1) ? row0 + 4 * u : row0;
+            mus[u] = mean[row]; rss[u] = rstd[row];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                int c = (lane + 64 * i) * 4;
+                if (c < C) {
+                    dv[u][i] = *reinterpret_cast<const float4*>(dy + (size_t)row * C + c);
+                    zv[u][i] = *reinterpret_cast<const float4*>(z + (size_t)row * C + c);
+                }
             }
         }
-        const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
-        uint32_t rkey = drop_thresh ? rng_row_key(seed, stream, (uint32_t)row) : 0u;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            int c = (lane + 64 * i) * 4;
-            if (c < C) {
-                float4 o;
-                o.x = rs * (g[i].x - c1 - xh[i].x * c2);
-                o.y = rs * (g[i].y - c1 - xh[i].y * c2);
-                o.z = rs * (g[i].z - c1 - xh[i].z * c2);
-                o.w = rs * (g[i].w - c1 - xh[i].w * c2);
-                *reinterpret_cast<float4*>(dz + (size_t)row * C + c) = o;
-                if (dz_drop) {
-                    float4 od;
-                    od.x = rng_keep(rkey, c + 0, drop_thresh) ? o.x * drop_scale : 0.f;
-                    od.y = rng_keep(rkey, c + 1, drop_thresh) ? o.y * drop_scale : 0.f;
-                    od.z = rng_keep(rkey, c + 2, drop_thresh) ? o.z * drop_scale : 0.f;
-                    od.w = rng_keep(rkey, c + 3, drop_thresh) ? o.w * drop_scale : 0.f;
-                    *reinterpret_cast<float4*>(dz_drop + (size_t)row * C + c) = od;
+        for (int u = 0; u < RU; ++u) {
+            const int row = row0 + 4 * u;
+            if (row >= r1) break;                            // wave-uniform
+            const float mu = mus[u], rs = rss[u];
+            float4 xh[NV], g[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                int c = (lane + 64 * i) * 4;
+                if (c < C) {
+                    const float4 d = dv[u][i], zz = zv[u][i];
+                    xh[i] = make_float4((zz.x - mu) * rs, (zz.y - mu) * rs, (zz.z - mu) * rs, (zz.w - mu) * rs);
+                    g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+                    s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                    s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                    ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+                    ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+                }
+            }
+            const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
+            uint32_t rkey = drop_thresh ? rng_row_key(seed, stream, (uint32_t)row) : 0u;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                int c = (lane + 64 * i) * 4;
+                if (c < C) {
+                    float4 o;
+                    o.x = rs * (g[i].x - c1 - xh[i].x * c2);
+                    o.y = rs * (g[i].y - c1 - xh[i].y * c2);
+                    o.z = rs * (g[i].z - c1 - xh[i].z * c2);
+                    o.w = rs * (g[i].w - c1 - xh[i].w * c2);
+                    *reinterpret_cast<float4*>(dz + (size_t)row * C + c) = o;
+                    if (dz_drop) {
+                        float4 od;
+                        od.x = rng_keep(rkey, c + 0, drop_thresh) ? o.x * drop_scale : 0.f;
+                        od.y = rng_keep(rkey, c + 1, drop_thresh) ? o.y * drop_scale : 0.f;
+                        od.z = rng_keep(rkey, c + 2, drop_thresh) ? o.z * drop_scale : 0.f;
+                        od.w = rng_keep(rkey, c + 3, drop_thresh) ? o.w * drop_scale : 0.f;
+                        *reinterpret_cast<float4*>(dz_drop + (size_t)row * C + c) = od;
+                    }
                 }
             }
         }
@@ -124,7 +147,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     if (!part) return;
     // block reduction of the column partials (4 waves); one row of [2][C] partials per workgroup, summed by ln_bwd_finalize
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = (lane + 64 * i) * 4;
         if (c < C) {
             *reinterpret_cast<float4*>(&red[0][wave][c]) = ag[i];
@@ -390,8 +413,12 @@ extern "C" int unast_layernorm_bwd(const float* dy, const float* z, const float*
     ln_bwd_geometry(rows, &blocks, &rpb);
     UNAST_REQUIRE(!dgamma || (ws && ws_floats >= (int64_t)blocks * 2 * C), "unast_layernorm_bwd: workspace too small (need %lld floats)", (long long)blocks * 2 * C);
     uint32_t th = dz_drop ? drop_threshold(drop_p) : 0u;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, z, gamma, mean, rstd, dz,
-                       (th ? dz_drop : (float*)nullptr), (dgamma ? ws : (float*)nullptr), rows, C, rpb, th, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, stream_id);
+    float* const dzd = th ? dz_drop : (float*)nullptr;
+    float* const prt = dgamma ? ws : (float*)nullptr;
+    const float dsc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    if (C <= 256)      hipLaunchKernelGGL((layernorm_bwd_kernel<1, 4>), dim3(blocks), dim3(256), 0, stream, dy, z, gamma, mean, rstd, dz, dzd, prt, rows, C, rpb, th, dsc, seed, stream_id);
+    else if (C <= 512) hipLaunchKernelGGL((layernorm_bwd_kernel<2, 2>), dim3(blocks), dim3(256), 0, stream, dy, z, gamma, mean, rstd, dz, dzd, prt, rows, C, rpb, th, dsc, seed, stream_id);
+    else               hipLaunchKernelGGL((layernorm_bwd_kernel<4, 1>), dim3(blocks), dim3(256), 0, stream, dy, z, gamma, mean, rstd, dz, dzd, prt, rows, C, rpb, th, dsc, seed, stream_id);
     if (dgamma && finalize) hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, ws, blocks, C, dgamma, dbeta);
     return unast_check_launch("unast_layernorm_bwd");
 }
