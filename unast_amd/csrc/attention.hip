@@ -314,7 +314,7 @@ __global__ __launch_bounds__(128 * (4 / QS), (QS == 1 ? 4 : 2)) void attn_q_kern
                             const float v = s[ks][qs][r];
                             pv = __builtin_amdgcn_exp2f(__builtin_fmaf(v, ssc, -mref));      // masked entries: exp2(-1e30 * ssc - m) = 0
                             rs += pv;
-                            s[ks][qs][r] = keep ? pv * p.drop_scale : 0.f;
+                            s[ks][qs][r] = keep ? pv : 0.f;          // 1/(1-p) is applied once, in the epilogue's normalisation
                         } else {
                             pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ks][qs][r], ssc, -mref));
                             if (MASKED) {
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(128 * (4 / QS), (QS == 1 ? 4 : 2)) void attn_q_kern
     for (int qs = 0; qs < QS; ++qs) {
         const int q = q0 + 16 * qs + l15;
         if (q >= p.Tq) continue;
-        const float f = (MODE == 0) ? (lsum[qs] > 0.f ? 1.f / lsum[qs] : 0.f) : p.scale;
+        const float f = (MODE == 0) ? (lsum[qs] > 0.f ? p.drop_scale / lsum[qs] : 0.f) : p.scale;
         float* dst = p.O + ((size_t)b * p.Tq + q) * p.ldo + h * HD + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
@@ -547,11 +547,11 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
                         float pd = pv, dpe = dp[qs][ks][r];
                         if (p.drop_thresh) {
                             const bool keep = rng_keep(rkey, (uint32_t)key, p.drop_thresh);
-                            pd = keep ? pv * p.drop_scale : 0.f;
-                            dpe = keep ? dpe * p.drop_scale : 0.f;
+                            pd = keep ? pv : 0.f;
+                            dpe = keep ? dpe : 0.f;
                         }
-                        s[qs][ks][r] = pd;                       // dropped probabilities (B operand of dV)
-                        dp[qs][ks][r] = pv * (dpe - de);         // dS (B operand of dK)
+                        s[qs][ks][r] = pd;                       // kept probabilities (B operand of dV; 1/(1-p) is applied to dV in the epilogue)
+                        dp[qs][ks][r] = pv * __builtin_fmaf(dpe, p.drop_scale, -de);         // dS (B operand of dK)
                     }
                 }
         };
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             *reinterpret_cast<float4*>(dkp + 16 * dt) = make_float4(dk[dt][ks][0] * p.scale, dk[dt][ks][1] * p.scale, dk[dt][ks][2] * p.scale, dk[dt][ks][3] * p.scale);
-            *reinterpret_cast<float4*>(dvp + 16 * dt) = make_float4(dv[dt][ks][0], dv[dt][ks][1], dv[dt][ks][2], dv[dt][ks][3]);
+            *reinterpret_cast<float4*>(dvp + 16 * dt) = make_float4(dv[dt][ks][0] * p.drop_scale, dv[dt][ks][1] * p.drop_scale, dv[dt][ks][2] * p.drop_scale, dv[dt][ks][3] * p.drop_scale);
         }
     }
 }
