@@ -45,6 +45,7 @@ WORKLOADS = {
     "c2": (8, 128, 512, 3, False),      # configs[1]: generator-only
     "c5": (32, 300, 2000, 4, True),     # configs[4]: long-form
     "tiny": (2, 24, 64, 2, True),
+    "c3-nodisc": (32, 180, 800, 4, False),   # diagnostic: what the discriminator's streams cost the config-3 step
 }
 
 
