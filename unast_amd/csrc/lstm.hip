@@ -43,11 +43,25 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
     }
     const float bias = b_ih[dir * bias_dir_stride + j] + b_hh[dir * bias_dir_stride + j];
     h_lds[wave][u] = 0.f;
+    if (len <= 0) {                                                  // (uniform) empty sequence: final state = initial state
+        if (wave == 0) hfinal[(size_t)b * (ndir * LH) + dir * LH + u] = 0.f;
+        return;
+    }
     float c = 0.f, h = 0.f;
     const size_t xs = (size_t)ndir * LG;
     const float* xp = xproj + (size_t)b * T * xs + (size_t)dir * LG + j;
     const int tstep = dir ? -1 : 1;
     const int t0 = dir ? len - 1 : 0;
+    // Output pointers of the first step, advanced by one time step per iteration (the 64-bit row arithmetic per step was
+    // a fifth of the step's instructions, all of them on its dependent chain).
+    const size_t row0 = ((size_t)b * T + t0) * ndir + dir;
+    float* gp = gates + row0 * LG + j;
+    float* hp = hprev + row0 * LH + u;
+    float* cp = cs + row0 * LH + u;
+    float* yp = y + ((size_t)b * T + t0) * ((size_t)ndir * LH) + dir * LH + u;
+    const ptrdiff_t g_inc = (ptrdiff_t)tstep * ndir * LG, h_inc = (ptrdiff_t)tstep * ndir * LH, y_inc = (ptrdiff_t)tstep * ndir * LH;
+    // sigmoid(x) = 1 / (1 + exp(-x)), tanh(x) = 2 / (1 + exp(-2x)) - 1: one branch-free form with wave-uniform constants (wave 2 = g)
+    const float act_m = (wave == 2) ? -2.f : -1.f, act_s = (wave == 2) ? 2.f : 1.f, act_o = (wave == 2) ? -1.f : 0.f;
     float xc[FCH], xn[FCH];
     auto load_chunk = [&](int s0, float (&x)[FCH]) {
 #pragma unroll
@@ -56,39 +70,38 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
             x[i] = xp[(size_t)(t0 + st * tstep) * xs];
         }
     };
-    if (len > 0) load_chunk(0, xn);
+    load_chunk(0, xn);
     for (int s0 = 0; s0 < len; s0 += FCH) {
 #pragma unroll
         for (int i = 0; i < FCH; ++i) xc[i] = xn[i];                // the only wait for global loads: once per chunk
         if (s0 + FCH < len) load_chunk(s0 + FCH, xn);
 #pragma unroll
         for (int i = 0; i < FCH; ++i) {
-            const int step = s0 + i;
-            if (step >= len) break;
-            const int t = t0 + step * tstep;
-            f32x2 a01 = {xc[i] + bias, 0.f}, a23 = {0.f, 0.f};      // four partial sums as two packed accumulators
+            if (s0 + i < len) {                                      // (uniform; a guard, not a break, so that the chunk unrolls and xc[i] is a register)
+                f32x2 a0 = {xc[i] + bias, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};     // four independent chains of 8 packed FMAs
 #pragma unroll
-            for (int k = 0; k < LH; k += 4) {
-                float4 hv = *reinterpret_cast<const float4*>(&h_lds[wave][k]);
-                a01 = __builtin_elementwise_fma(w[k / 2], (f32x2){hv.x, hv.y}, a01);
-                a23 = __builtin_elementwise_fma(w[k / 2 + 1], (f32x2){hv.z, hv.w}, a23);
+                for (int k = 0; k < LH; k += 8) {
+                    const float4 hv0 = *reinterpret_cast<const float4*>(&h_lds[wave][k]);
+                    const float4 hv1 = *reinterpret_cast<const float4*>(&h_lds[wave][k + 4]);
+                    a0 = __builtin_elementwise_fma(w[k / 2], (f32x2){hv0.x, hv0.y}, a0);
+                    a1 = __builtin_elementwise_fma(w[k / 2 + 1], (f32x2){hv0.z, hv0.w}, a1);
+                    a2 = __builtin_elementwise_fma(w[k / 2 + 2], (f32x2){hv1.x, hv1.y}, a2);
+                    a3 = __builtin_elementwise_fma(w[k / 2 + 3], (f32x2){hv1.z, hv1.w}, a3);
+                }
+                const float pre = ((a0[0] + a0[1]) + (a1[0] + a1[1])) + ((a2[0] + a2[1]) + (a3[0] + a3[1]));
+                const float act = __builtin_fmaf(__builtin_amdgcn_rcpf(1.f + __expf(act_m * pre)), act_s, act_o);
+                float* gl = g_lds[i & 1];
+                gl[j] = act;
+                *gp = act;
+                __syncthreads();
+                const float ig = gl[u], fg = gl[LH + u], gg = gl[2 * LH + u], og = gl[3 * LH + u];
+                if (wave == 0) *hp = h;
+                c = fg * c + ig * gg;
+                h = og * tanhf_(c);
+                if (wave == 0) { *cp = c; *yp = h; }
+                h_lds[wave][u] = h;           // same-wave LDS write -> read ordering: no barrier needed
+                gp += g_inc; hp += h_inc; cp += h_inc; yp += y_inc;
             }
-            const float pre = (a01[0] + a01[1]) + (a23[0] + a23[1]);
-            const float act = (wave == 2) ? tanhf_(pre) : sigmoidf_(pre);        // wave-uniform: waves = i,f,g,o
-            float* gl = g_lds[i & 1];
-            gl[j] = act;
-            const size_t row = ((size_t)b * T + t) * ndir + dir;
-            gates[row * LG + j] = act;
-            __syncthreads();
-            const float ig = gl[u], fg = gl[LH + u], gg = gl[2 * LH + u], og = gl[3 * LH + u];
-            if (wave == 0) hprev[row * LH + u] = h;
-            c = fg * c + ig * gg;
-            h = og * tanhf_(c);
-            if (wave == 0) {
-                cs[row * LH + u] = c;
-                y[((size_t)b * T + t) * (ndir * LH) + dir * LH + u] = h;
-            }
-            h_lds[wave][u] = h;           // same-wave LDS write -> read ordering: no barrier needed
         }
     }
     if (wave == 0) hfinal[(size_t)b * (ndir * LH) + dir * LH + u] = h;
@@ -131,7 +144,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
             v[i][6] = dy ? dy[((size_t)b * T + t) * (ndir * LH) + dir * LH + k] : 0.f;
         }
     };
-    if (len > 0) load_chunk(0, vn);
+    if (len <= 0) return;                                   // (uniform)
+    float* dgr = dgates + (((size_t)b * T + t0) * ndir + dir) * LG + k;        // advanced by one time step per iteration
+    const ptrdiff_t dg_inc = (ptrdiff_t)tstep * ndir * LG;
+    load_chunk(0, vn);
     for (int r0 = 0; r0 < len; r0 += BCH) {
 #pragma unroll
         for (int i = 0; i < BCH; ++i)
@@ -141,8 +157,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             const int r = r0 + i;
-            if (r >= len) break;
-            const int t = t0 + r * tstep;
+            if (r < len) {                                  // (uniform; a guard, not a break, so that the chunk unrolls)
             const float ig = vc[i][0], fg = vc[i][1], gg = vc[i][2], og = vc[i][3], ct = vc[i][4];
             const float cprev = (r == len - 1) ? 0.f : vc[i][5];
             const float dht = dh + vc[i][6];
@@ -155,21 +170,23 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
             dc = dct * fg;
             float* dgw = dg_lds[part];
             dgw[k] = d_i; dgw[LH + k] = d_f; dgw[2 * LH + k] = d_g; dgw[3 * LH + k] = d_o;
-            if (part == 0) {
-                float* dgr = dgates + (((size_t)b * T + t) * ndir + dir) * LG;
-                dgr[k] = d_i; dgr[LH + k] = d_f; dgr[2 * LH + k] = d_g; dgr[3 * LH + k] = d_o;
-            }
-            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+            if (part == 0) { dgr[0] = d_i; dgr[LH] = d_f; dgr[2 * LH] = d_g; dgr[3 * LH] = d_o; }
+            dgr += dg_inc;
+            f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};      // four independent chains of 8 packed FMAs
 #pragma unroll
-            for (int ii = 0; ii < LH; ii += 4) {
-                float4 dv = *reinterpret_cast<const float4*>(&dgw[part * LH + ii]);      // written by this wave just above
-                a01 = __builtin_elementwise_fma(wt[ii / 2], (f32x2){dv.x, dv.y}, a01);
-                a23 = __builtin_elementwise_fma(wt[ii / 2 + 1], (f32x2){dv.z, dv.w}, a23);
+            for (int ii = 0; ii < LH; ii += 8) {
+                const float4 dv0 = *reinterpret_cast<const float4*>(&dgw[part * LH + ii]);      // written by this wave just above
+                const float4 dv1 = *reinterpret_cast<const float4*>(&dgw[part * LH + ii + 4]);
+                a0 = __builtin_elementwise_fma(wt[ii / 2], (f32x2){dv0.x, dv0.y}, a0);
+                a1 = __builtin_elementwise_fma(wt[ii / 2 + 1], (f32x2){dv0.z, dv0.w}, a1);
+                a2 = __builtin_elementwise_fma(wt[ii / 2 + 2], (f32x2){dv1.x, dv1.y}, a2);
+                a3 = __builtin_elementwise_fma(wt[ii / 2 + 3], (f32x2){dv1.z, dv1.w}, a3);
             }
             float (*pl)[LH] = part_lds[i & 1];
-            pl[part][k] = (a01[0] + a01[1]) + (a23[0] + a23[1]);
+            pl[part][k] = ((a0[0] + a0[1]) + (a1[0] + a1[1])) + ((a2[0] + a2[1]) + (a3[0] + a3[1]));
             __syncthreads();
             dh = (pl[0][k] + pl[1][k]) + (pl[2][k] + pl[3][k]);
+            }
         }
     }
 }
