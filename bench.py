@@ -200,8 +200,9 @@ def main():
     ap.add_argument("--cpu-budget", type=int, default=110, help="seconds of CPU-oracle stepping (1 warm-up + up to 3 timed steps of the same batch)")
     ap.add_argument("--launch", default=os.environ.get("UNAST_LAUNCH"), choices=["auto", "graph", "eager"],
                     help="graph = replay the captured step (unast_amd.graphed), eager = one Python launch per kernel, auto = time a few untimed "
-                         "steps of each before the warm-up and keep the faster.  Default: eager for the GPU-bound configurations (c3, c5: "
-                         "replay ties eager there, 32.9 vs 32.9 ms/step), auto for the host-bound ones (c2, tiny: 9.6 vs 17.2 ms/step)")
+                         "steps of each before the warm-up and keep the faster (the default: at config 3 the two tie on a box with a fast "
+                         "host -- 31.0 vs 31.0 ms/step -- and the replay wins where eager enqueue, 26-30 ms/step, gets close to the GPU's "
+                         "30 ms; at config 2 the replay is 9.3 against 17 ms/step)")
     ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
     ap.add_argument("--iso-detail", action="store_true", help="print the per-shape table of the isolated steps to stderr")
     ap.add_argument("--iso-steps", type=int, default=2, help="single-stream eager steps after the timed region whose GEMM / attention launches are timed with HIP events")
@@ -259,7 +260,7 @@ def main():
     losses = defaultdict(list)
 
     can_graph = a.cm_steps == 0 and not dist_on and not a.profile_ops and a.time_every == 0
-    launch = "eager" if (a.no_graph or not can_graph) else (a.launch or ("eager" if a.workload in ("c3", "c5") else "auto"))
+    launch = "eager" if (a.no_graph or not can_graph) else (a.launch or "auto")
     stepper = None
     auto_note = None
     if launch in ("graph", "auto"):
@@ -284,7 +285,7 @@ def main():
         one_step(i)
     if launch == "auto":
         # untimed calibration: a few steps of each launch mode, keep the faster
-        def probe(fn, n=4):
+        def probe(fn, n=6):
             fn(0); sync()
             t = time.perf_counter()
             for i in range(n):
@@ -296,7 +297,7 @@ def main():
         ms_eager = probe(lambda i: train.train_step(losses, model, opt, sched, batches, i, args, defer_d_phase=True))
         from unast_amd.engine import join_streams
         join_streams(); sync()
-        auto_note = "auto: graph replay %.2f ms/step vs eager %.2f ms/step in 4 untimed steps each" % (ms_graph, ms_eager)
+        auto_note = "auto: graph replay %.2f ms/step vs eager %.2f ms/step in 6 untimed steps each" % (ms_graph, ms_eager)
         if ms_eager < ms_graph:
             stepper = None
     for i in range(a.warmup):
