@@ -45,7 +45,11 @@ const char* unast_arch(void);
  *           unast_split_f32 (same byte offsets as the fp32 weights), so the kernel does not re-split them per row panel.
  * out_split: C is stored in that same format (per 4 consecutive columns one 16-byte chunk [hi x4 | lo x4] of bf16 at the fp32
  *           byte offset): the in-projection outputs Q / K / V and the out-projection's input gradient dO, which only the
- *           attention kernels read (qkv_split there); needs N % 4 == 0, beta = 0, no split-K. */
+ *           attention kernels read (qkv_split there); needs N % 4 == 0, beta = 0, no split-K.
+ * colstats: (conv forward form only: a_mode = OP_KC_CONV, b_mode = OP_KC, bias-only epilogue) 2*N doubles, zeroed by the caller, that
+ *           receive sum_m C[m][n] and sum_m C[m][n]^2: the batch statistics of the BatchNorm1d that follows every Conv1d of the
+ *           prenet / postnet stacks (src/module.py:162-165, 223-230), taken in the GEMM epilogue instead of by a pass over C
+ *           (unast_bn_fwd have_sums = 1).  NULL: not computed. */
 int unast_gemm(int a_mode, int b_mode, int nsplit,
                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                int M, int N, int K, int kb_valid,
@@ -54,7 +58,7 @@ int unast_gemm(int a_mode, int b_mode, int nsplit,
                float alpha, int beta, int act,
                float drop_p, unsigned int seed, unsigned int stream_id,
                int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, int tile_wn, int b_presplit,
-               int out_split, hipStream_t stream);
+               int out_split, double* colstats, hipStream_t stream);
 
 /* Fused multi-head attention core (head_dim 64), flash-style.  Replaces the softmax(QK^T/sqrt(d)+mask) -> dropout -> V
  * core of torch.nn.MultiheadAttention inside torch.nn.TransformerEncoderLayer/DecoderLayer
@@ -94,12 +98,13 @@ int unast_colsum_f32(const float* x, int ldx, int rows, int C, float* sum, hipSt
 
 /* Train-mode BatchNorm1d + activation (1 relu, 2 tanh) + dropout over [rows=B*T, C]: TextPrenet.forward_fcn
  * (src/module.py:223-230) and SpeechPostnet.forward (src/module.py:162-165).  Updates running stats (momentum,
- * unbiased variance) when running_mean != NULL.  ws: 2*C doubles of scratch.
+ * unbiased variance) when running_mean != NULL.  ws: 2*C doubles of scratch; have_sums = 1: ws already holds the column
+ * sums and sums of squares of x (written by unast_gemm colstats), the statistics pass over x is skipped.
  * bwd: dy_inout is overwritten with d(pre-activation); dgamma/dbeta accumulated (may be NULL). */
 int unast_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                  float* running_mean, float* running_var, double* ws, int rows, int C,
                  float eps, float momentum, int act, float drop_p, unsigned int seed, unsigned int stream_id,
-                 hipStream_t stream);
+                 int have_sums, hipStream_t stream);
 /* Eval-mode BatchNorm1d + activation (model.eval(): running statistics, no dropout), as evaluate() runs it
  * (src/train.py:484; src/module.py:162-165, 223-230).  mean/rstd: C floats of scratch. */
 int unast_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,

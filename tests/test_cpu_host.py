@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for B in (C,):
         assert B.unast_version() >= 100 and B.unast_arch() == b"gfx950"
         # argument validation happens on the host before any launch: a null/invalid call must return an error, not crash
-        assert B.unast_gemm(0, 0, 3, None, 4, None, 4, None, 4, 1, 1, 1, 0, 0, 0, 0, 0, None, None, 0, None, 0, 1.0, 1.0, 0, 0, 0.0, 0, 0, 1, None, 0, None, 0, 0, 0, None) < 0
+        assert B.unast_gemm(0, 0, 3, None, 4, None, 4, None, 4, 1, 1, 1, 0, 0, 0, 0, 0, None, None, 0, None, 0, 1.0, 1.0, 0, 0, 0.0, 0, 0, 1, None, 0, None, 0, 0, 0, None, None) < 0
         assert b"null operand" in B.unast_last_error()
         assert B.unast_attn_fwd(2, None, 0, None, 0, None, 0, None, 0, None, None, 1, 1, 1, 1, 64, 0, 0.125, 0.0, 0, 0, 0, None) < 0
 

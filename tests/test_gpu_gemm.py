@@ -317,3 +317,35 @@ def _dgrad_T_body(st, opt):
     opt.zero_grad()
     assert not torch.equal(before, st.flat)
     check_all()
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout", [(3, 37, 80, 256), (32, 800, 256, 512), (2, 5, 256, 256), (5, 130, 512, 80)])
+def test_conv_forward_epilogue_column_statistics(B, T, Cin, Cout):
+    """unast_gemm colstats (the conv forward's epilogue) = per-channel sum and sum of squares of the conv output incl. bias, over
+    all B*T positions -- ragged row / column tiles included -- and BatchNorm from those sums equals BatchNorm from its own pass."""
+    from unast_amd import ops, config
+    config.NSPLIT = 3
+    D = dev()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, T, Cin, generator=g).to(D); Wp = (torch.randn(Cout, 5, Cin, generator=g) / (5 * Cin) ** 0.5).to(D); b = torch.randn(Cout, generator=g).to(D)
+    y = torch.empty(B, T, Cout, device=D); ws = torch.zeros(2 * Cout, dtype=torch.float64, device=D)
+    ops.conv_fwd(x, Wp, b, y, 2, colstats=ws)
+    y0 = torch.empty(B, T, Cout, device=D)
+    ops.conv_fwd(x, Wp, b, y0, 2)
+    assert torch.equal(y, y0)                                   # the statistics do not touch the output
+    yd = y.view(-1, Cout).double()
+    s1, s2 = yd.sum(0), (yd * yd).sum(0)
+    assert float((ws[:Cout] - s1).abs().max()) < 1e-4 * max(1.0, float(s1.abs().max()))
+    assert float(((ws[Cout:] - s2) / s2).abs().max()) < 1e-5
+    N = B * T
+    gamma = torch.randn(Cout, generator=g).to(D); beta = torch.randn(Cout, generator=g).to(D)
+    outs = []
+    for have in (True, False):
+        out = torch.empty(N, Cout, device=D); mean = torch.empty(Cout, device=D); rstd = torch.empty(Cout, device=D)
+        rm = torch.zeros(Cout, device=D); rv = torch.ones(Cout, device=D)
+        w = ws.clone() if have else torch.empty(2 * Cout, dtype=torch.float64, device=D)
+        ops.bn_fwd(y.view(N, Cout), gamma, beta, out, mean, rstd, rm, rv, w, 1, have_sums=have)
+        outs.append((out, mean, rstd, rm, rv))
+    for a, c in zip(outs[0], outs[1]):
+        assert relerr(a, c.cpu()) < 2e-5          # fp32 partial sums in a different order (variance = E[x^2] - E[x]^2 cancels at small B*T)
+

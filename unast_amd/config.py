@@ -61,3 +61,7 @@ DGRAD_TRANSPOSED = os.environ.get("UNAST_DGRAD_T", "0") == "1"
 # The in-projections write Q / K / V -- and the out-projection's input-gradient GEMM writes dO -- in the pre-split operand format;
 # the attention kernels then stage K/V (forward) and Q/dO (backward) tiles without fp32 -> hi/lo conversions.  0 = fp32 (A/B).
 ATTN_PRESPLIT = os.environ.get("UNAST_ATTN_PRESPLIT", "1") != "0"
+
+# BatchNorm batch statistics of the conv stacks taken in the conv GEMM's epilogue (unast_gemm colstats) instead of by a column-sum
+# pass over the conv output.  0 = the separate pass (A/B).
+CONV_BN_STATS = os.environ.get("UNAST_CONV_BN_STATS", "1") != "0"

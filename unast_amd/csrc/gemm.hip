@@ -40,6 +40,7 @@ struct GemmParams {
     float* rowsum_a;                                  // optional: rowsum_a[m] += sum_k A[m][k] (bias gradient fused into wgrad)
     int group;                                        // launched as one problem of a grouped weight-gradient launch (split-K tile map, slabs)
     int out_split;                                    // store C in the pre-split operand format (16-B chunks [hi x4 | lo x4]) for the attention kernels
+    double* colstats;                                 // conv forward only: colstats[n] += sum_m C[m][n], colstats[N + n] += sum_m C[m][n]^2 (BatchNorm batch statistics)
 };
 
 __device__ __forceinline__ int swz_h(int row) { return (0x1320 >> (((row >> 2) & 3) << 2)) & 3; }
@@ -100,6 +101,50 @@ __device__ __forceinline__ float4 load_rc(const GemmParams& p, const float* __re
 
 // Epilogue shared by the GEMM kernels: lane holds C[m = ..+l15][n = ..+4g .. 4g+3] of MI x 4 MFMA tiles; the wave's
 // sub-tile starts at (m0 + wm*16*MI, n0 + wn*64).
+// 16-lane row reduction (lanes that differ in l15 only) with DPP adds: every lane of the row ends up with the row's sum.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
+// Column sums of the tile (BatchNorm's batch statistics of a convolution's output, taken where the output is produced instead
+// of by a second pass over it): in-lane over the wave's MI row sub-tiles, DPP over the 16 rows of a sub-tile, LDS atomics over
+// the workgroup's waves, one fp64 atomic per column and moment per workgroup.  `red` = the (drained) operand stages.
+template <int MI, int GBN_, int WM_>
+__device__ __forceinline__ void gemm_colstats(const GemmParams& p, const f32x4 (&acc)[MI][4], float* red, int m0, int n0, int wm, int wn, int l15, int g, int t, int nthreads) {
+    __syncthreads();                                            // every wave is done reading the operand stages
+    // red[moment][wm][column]: one slot per wave row (no float atomics: the sums must not depend on which wave arrives first)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nl = wn * 64 + j * 16 + 4 * g;                // column inside the tile
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + nl + r;
+            const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * (16 * MI) + i * 16 + l15;
+                const float x = (m < p.M) ? acc[i][j][r] * p.alpha + bv : 0.f;
+                s1 += x; s2 += x * x;
+            }
+            s1 = row16_sum(s1); s2 = row16_sum(s2);
+            if (l15 == 0) { red[wm * GBN_ + nl + r] = s1; red[(WM_ + wm) * GBN_ + nl + r] = s2; }
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < 2 * GBN_; i += nthreads) {
+        const int mom = i / GBN_, c = i % GBN_, n = n0 + c;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM_; ++w) v += red[(mom * WM_ + w) * GBN_ + c];
+        if (n < p.N) unsafeAtomicAdd(p.colstats + (size_t)mom * p.N + n, (double)v);
+    }
+}
+
 template <int MI>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][4], int m0, int n0, int wm, int wn, int l15, int g, int zsplit) {
     // ---- epilogue: lane holds C[m = ..+l15][n = ..+4g .. 4g+3] --------------------------------------
@@ -395,6 +440,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int pid) {
         __syncthreads();
         if (t < 128 && m0 + t < p.M) atomicAdd(p.rowsum_a + m0 + t, red[t]);
     }
+    if constexpr (AM == OP_KC_CONV && BMODE == OP_KC) {        // (only the conv forward instantiations carry this code)
+        if (p.colstats) gemm_colstats<MI, GBN, WM>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, l15, g, t, NT);
+    }
     gemm_epilogue<MI>(p, acc, m0, n0, wm, wn, l15, g, zsplit);
 }
 
@@ -440,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GroupParams gp
     p.alpha = 1.f; p.beta = 1; p.act = 0; p.drop_thresh = 0u; p.drop_scale = 1.f; p.seed = 0u; p.stream = 0u;
     p.kchunk = it.kchunk; p.atomic = 0; p.tiles_m = it.tiles_m; p.tiles_n = it.tiles_n; p.nsplitk = it.nsplitk;
     p.slab = it.slab; p.ld_slab = it.ld_slab; p.slab_stride = (size_t)it.M * it.ld_slab;
-    p.kb_valid = it.K; p.rowsum_a = it.rowsum_a; p.group = 1; p.out_split = 0;
+    p.kb_valid = it.K; p.rowsum_a = it.rowsum_a; p.group = 1; p.out_split = 0; p.colstats = nullptr;
     gemm_body<OP_RC, OP_RC, NSPLIT, 2, 2, FLAGS>(p, b - gp.base[i]);
 }
 
@@ -589,7 +637,7 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
                           float alpha, int beta, int act,
                           float drop_p, unsigned int seed, unsigned int stream_id,
                           int splitk, float* splitk_ws, int64_t splitk_ws_floats, float* rowsum_a, int tile_wn, int b_presplit,
-                          int out_split, hipStream_t stream) {
+                          int out_split, double* colstats, hipStream_t stream) {
     UNAST_REQUIRE(A && B && C, "unast_gemm: null operand");
     UNAST_REQUIRE(!b_presplit || (a_mode == OP_KC || a_mode == OP_KC_CONV), "unast_gemm: a pre-split B is a weight (forward / dgrad forms only)");
     UNAST_REQUIRE(M > 0 && N > 0 && K > 0, "unast_gemm: bad dims M=%d N=%d K=%d", M, N, K);
@@ -612,7 +660,9 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     p.bias = bias; p.R = R; p.ldr = ldr; p.G = G; p.ldg = ldg; p.gate_scale = gate_scale;
     p.alpha = alpha; p.beta = beta; p.act = act;
     p.drop_thresh = drop_threshold(drop_p); p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    p.seed = seed; p.stream = stream_id; p.group = 0; p.out_split = out_split;
+    p.seed = seed; p.stream = stream_id; p.group = 0; p.out_split = out_split; p.colstats = colstats;
+    UNAST_REQUIRE(!colstats || (a_mode == OP_KC_CONV && b_mode == OP_KC && splitk == 1 && !act && drop_p <= 0.f && !R && !G && beta == 0),
+                  "unast_gemm: colstats is for the plain conv forward (bias only)");
     UNAST_REQUIRE(!out_split || ((N & 3) == 0 && (ldc & 3) == 0 && beta == 0 && splitk == 1), "unast_gemm: out_split needs N %% 4 == 0, ldc %% 4 == 0, beta = 0, no split-K");
     // tile width: 128x256 when N is wide enough and the grid still fills the chip; `tile_wn` (2/4) overrides, 0 = auto
     int wn = tile_wn;

@@ -459,12 +459,14 @@ extern "C" int unast_colsum_f32(const float* x, int ldx, int rows, int C, float*
 extern "C" int unast_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                             float* running_mean, float* running_var, double* ws /* 2*C doubles */, int rows, int C,
                             float eps, float momentum, int act, float drop_p, unsigned int seed, unsigned int stream_id,
-                            hipStream_t stream) {
+                            int have_sums, hipStream_t stream) {
     UNAST_REQUIRE(x && gamma && beta && y && mean && rstd && ws, "unast_bn_fwd: null pointer");
     int blocks, rpb;
     UNAST_REQUIRE(colsum_geometry(rows, C, &blocks, &rpb) == 0, "unast_bn_fwd: need C%%4==0, C<=1024 (C=%d)", C);
-    hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream);
-    hipLaunchKernelGGL((colsum_kernel<double>), dim3(blocks), dim3(256), 0, stream, x, C, rows, C, rpb, ws, ws + C);
+    if (!have_sums) {       // have_sums: ws already holds sum x | sum x^2 per column (the producing conv GEMM's epilogue, unast_gemm colstats)
+        hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream);
+        hipLaunchKernelGGL((colsum_kernel<double>), dim3(blocks), dim3(256), 0, stream, x, C, rows, C, rpb, ws, ws + C);
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, ws + C, C, (double)rows, eps, momentum,
                        mean, rstd, running_mean, running_var);
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for((size_t)rows * (C / 4), 256)), dim3(256), 0, stream, x, mean, rstd, gamma, beta, y,

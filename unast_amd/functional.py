@@ -236,17 +236,21 @@ def conv_bn_act(cx, tape, x, B, T, conv_pre, bn_pre, pad_left, act, drop, bn_buf
     Cout, _, Cin = Wp.shape
     x3 = x.v.view(B, T, -1)[..., :Cin] if x.v.shape[1] != Cin else x.v.view(B, T, Cin)
     c = _empty(B, T, Cout, like=x.v)
-    ops.conv_fwd(x3, Wp, b, c, pad_left)
+    fused_stats = cx.training and config.CONV_BN_STATS
+    if fused_stats:          # sum / sum of squares per channel come out of the conv GEMM's epilogue
+        ws = torch.zeros(2 * Cout, dtype=torch.float64, device=x.v.device)
+    else:
+        ws = torch.empty(2 * Cout, dtype=torch.float64, device=x.v.device)
+    ops.conv_fwd(x3, Wp, b, c, pad_left, colstats=ws if fused_stats else None)
     p = cx.p(drop)
     s = cx.stream()
     N = B * T
     y = _empty(N, Cout, like=x.v)
     mean, rstd = _empty(Cout, like=x.v), _empty(Cout, like=x.v)
-    ws = torch.empty(2 * Cout, dtype=torch.float64, device=x.v.device)
     rm, rv = bn_buffers[bn_pre + "running_mean"], bn_buffers[bn_pre + "running_var"]
     gamma, beta = cx.P[bn_pre + "weight"], cx.P[bn_pre + "bias"]
     if cx.training:
-        ops.bn_fwd(c.view(N, Cout), gamma, beta, y, mean, rstd, rm, rv, ws, act, drop_p=p, seed=cx.seed, stream_id=s)
+        ops.bn_fwd(c.view(N, Cout), gamma, beta, y, mean, rstd, rm, rv, ws, act, drop_p=p, seed=cx.seed, stream_id=s, have_sums=fused_stats)
         bn_buffers[bn_pre + "num_batches_tracked"] += 1
     else:
         if tape is not None:

@@ -67,7 +67,7 @@ def _transposed_weight(W):
 
 def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bias=None, R=None, ldr=0, G=None,
          ldg=0, gate_scale=1.0, alpha=1.0, beta=0, act=0, drop_p=0.0, seed=0, stream_id=0, splitk=1, nsplit=None, atomic=False, rowsum_a=None, kb_valid=0, tile_wn=0,
-         b_ptr=None, out_split=False):
+         b_ptr=None, out_split=False, colstats=None):
     """out_split: C is written in the pre-split operand format (for the attention kernels).  b_ptr: B given as a raw device pointer to a PRE-SPLIT operand (a transposed weight copy); `B` is then only a shape/dtype witness."""
     if A.dtype is not _F32 or B.dtype is not _F32 or C.dtype is not _F32 or not C.is_cuda:       # (epilogue operands are produced by this package)
         for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (R, "R"), (G, "G")):
@@ -86,7 +86,7 @@ def gemm(a_mode, b_mode, A, lda, B, ldb, C, ldc, M, N, K, conv=(0, 0, 0, 0), bia
     check(lib().unast_gemm(a_mode, b_mode, nsplit or config.NSPLIT, _p(A), lda, bp, ldb, _p(C), ldc, M, N, K, kb_valid,
                            conv[0], conv[1], conv[2], conv[3], _p(bias), _p(R), ldr, _p(G), ldg, gate_scale,
                            alpha, beta, act, drop_p, seed & 0xFFFFFFFF, stream_id, splitk, _p(ws), ws_n, _p(rowsum_a), tile_wn, presplit,
-                           int(out_split), _stream()), "unast_gemm")
+                           int(out_split), _p(colstats), _stream()), "unast_gemm")
 
 
 import os as _os
@@ -291,12 +291,13 @@ def linear_wgrad(dy2d, x2d, dW, db=None):
     return _linear_wgrad_now(dy2d, x2d, dW, db)
 
 
-def conv_fwd(x3d, Wp, bias, out, pad_left):
-    """x3d [B,T,Cin], Wp [Cout,5,Cin] (tap-major physical layout), out [B,T,Cout]."""
+def conv_fwd(x3d, Wp, bias, out, pad_left, colstats=None):
+    """x3d [B,T,Cin], Wp [Cout,5,Cin] (tap-major physical layout), out [B,T,Cout].  colstats: float64 [2*Cout], zeroed by the
+    caller, receives the per-channel sum and sum of squares of `out` (the batch statistics of the BatchNorm that follows)."""
     B, T, Cin = x3d.shape
     Cout = Wp.shape[0]
     gemm(OP_KC_CONV, OP_KC, x3d, x3d.stride(1), Wp, 5 * Cin, out, out.stride(1), B * T, Cout, 5 * Cin,
-         conv=(T, Cin, 0, pad_left), bias=bias)
+         conv=(T, Cin, 0, pad_left), bias=bias, colstats=colstats)
     return out
 
 
@@ -359,10 +360,10 @@ def colsum(x2d, out):
     check(lib().unast_colsum_f32(_p(x2d), x2d.stride(0), rows, C, _p(out), _stream()), "unast_colsum_f32")
 
 
-def bn_fwd(x2d, gamma, beta, y, mean, rstd, running_mean, running_var, ws, act, drop_p=0.0, seed=0, stream_id=0, eps=1e-5, momentum=0.1):
+def bn_fwd(x2d, gamma, beta, y, mean, rstd, running_mean, running_var, ws, act, drop_p=0.0, seed=0, stream_id=0, eps=1e-5, momentum=0.1, have_sums=False):
     rows, C = x2d.shape
     check(lib().unast_bn_fwd(_p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(running_mean), _p(running_var), _p(ws), rows, C,
-                             eps, momentum, act, drop_p, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_bn_fwd")
+                             eps, momentum, act, drop_p, seed & 0xFFFFFFFF, stream_id, int(have_sums), _stream()), "unast_bn_fwd")
 
 
 def bn_eval_fwd(x2d, gamma, beta, running_mean, running_var, y, mean, rstd, act, eps=1e-5):
