@@ -393,11 +393,23 @@ def main():
                 break
             except Exception:
                 traffic = None
+    rocprof_avg = None           # the same family's average launch duration in the committed single-stream rocprofv3 summary
+    for cp in ("r02_d_bench_c3_single_stream_kernel_stats.csv", "r02_b_bench_c3_single_stream_kernel_stats.csv"):
+        cp = os.path.join(ROOT, "profiles", cp)
+        if a.workload == "c3" and config.NSPLIT == 3 and os.path.exists(cp):
+            try:
+                import csv
+                rows = [r for r in csv.DictReader(open(cp)) if r["Name"].startswith("void gemm_kernel") or "gemm_group_kernel" in r["Name"]]
+                rocprof_avg = round(sum(int(r["TotalDurationNs"]) for r in rows) / sum(int(r["Calls"]) for r in rows) / 1e3, 2)
+                break
+            except Exception:
+                rocprof_avg = None
     roofline = {"kernel": "gemm_kernel<*,*,%d> (all linear / conv contractions: forward, dgrad, grouped wgrad)" % config.NSPLIT,
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": round(g["bytes"] / max(g["calls"], 1), 0),
                 "launches_per_step": g["calls"] / steps_iso, "avg_launch_us": round(g["ms"] * 1e3 / max(g["calls"], 1), 2),
                 "ms_per_step": round(g["ms"] / steps_iso, 3), "measured_over": "%d single-stream eager step(s) after the timed region" % a.iso_steps,
+                "rocprof_avg_launch_us": rocprof_avg,
                 "mfma_view": {"achieved_tflops": round(gtf, 2), "frac_of_2500_dense_bf16": round(gtf / PEAK_MFMA_BF16_TFLOPS, 4),
                               "mfma_issue_tflops": round(gtf * config.NSPLIT, 1), "sustained_mfma_peak_measured_tflops": SUSTAINED_MFMA_TFLOPS},
                 "attn_fwd": mfma_entry("attn_fwd", "attn_q_kernel<%d,0>" % config.NSPLIT),
@@ -406,7 +418,9 @@ def main():
                         "per tap) / HIP-event time of these launches, taken on the launch stream in the isolated single-stream steps after the "
                         "timed region (inside the timed region a launch shares the chip with the kernels of the other three streams, and a replayed "
                         "capture has no per-kernel host hooks); traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE per launch "
-                        "from profiles/ (separate rocprofv3 passes of this command), null if absent; mfma_view / attn_*: 2MNK FLOPs per "
+                        "from profiles/ (separate rocprofv3 passes of this command), null if absent; rocprof_avg_launch_us = the family's average kernel "
+                        "duration in the committed single-stream rocprofv3 summary (profiles/r02_d_*): avg_launch_us brackets each launch with a "
+                        "HIP-event pair and so carries ~4 us of dispatch per launch on top of it; mfma_view / attn_*: 2MNK FLOPs per "
                         "contraction, 4*B*H*Tq*Tk*64 per attention forward (x2.5 backward, causal at T(T+1)/2); each product costs %d bf16 MFMAs in "
                         "%s mode; sustained MFMA peak = tools/mfma_peak.cpp on this chip" % (config.NSPLIT, a.precision)}
     if in_region and n_timed:
