@@ -165,9 +165,10 @@ def test_attention_dropout_consistency():
     assert not torch.allclose(O1, O2)
 
 
-def test_layernorm_fwd_bwd():
+@pytest.mark.parametrize("rows,C", [(333, 256), (1, 256), (37, 80), (130, 512), (65, 1024), (4099, 256)])
+def test_layernorm_fwd_bwd(rows, C):
+    """Every width class of the backward kernel (<= 256, <= 512, <= 1024 columns) and row counts that leave the four-row unroll a tail."""
     from unast_amd import ops
-    rows, C = 333, 256
     g = torch.Generator().manual_seed(1)
     z = (torch.randn(rows, C, generator=g, dtype=torch.float64) * 2 + 0.3).requires_grad_(True)
     w = torch.randn(C, generator=g, dtype=torch.float64).requires_grad_(True)
@@ -186,7 +187,7 @@ def test_layernorm_fwd_bwd():
     dzd = torch.empty(rows, C, device=D)
     ops.layernorm_bwd(dy.float().to(D), z.detach().float().to(D), w.detach().float().to(D), mean, rstd, dz, dzd, None, None, drop_p=0.1, seed=3, stream_id=9)
     keep = dzd != 0
-    assert abs(keep.float().mean().item() - 0.9) < 0.01
+    assert abs(keep.float().mean().item() - 0.9) < (0.01 if rows * C > 50000 else 0.08)
     assert torch.allclose(dzd[keep], dz[keep] / 0.9, rtol=1e-5)
     # the same (seed, stream) mask as the GEMM epilogue dropout
     x = torch.ones(rows, 64, device=D); W = torch.ones(C, 64, device=D)
