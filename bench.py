@@ -394,7 +394,7 @@ def main():
             except Exception:
                 traffic = None
     rocprof_avg = None           # the same family's average launch duration in the committed single-stream rocprofv3 summary
-    for cp in ("r02_d_bench_c3_single_stream_kernel_stats.csv", "r02_b_bench_c3_single_stream_kernel_stats.csv"):
+    for cp in ("r02_f_bench_c3_single_stream_kernel_stats.csv", "r02_d_bench_c3_single_stream_kernel_stats.csv", "r02_b_bench_c3_single_stream_kernel_stats.csv"):
         cp = os.path.join(ROOT, "profiles", cp)
         if a.workload == "c3" and config.NSPLIT == 3 and os.path.exists(cp):
             try:
@@ -419,7 +419,7 @@ def main():
                         "timed region (inside the timed region a launch shares the chip with the kernels of the other three streams, and a replayed "
                         "capture has no per-kernel host hooks); traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE per launch "
                         "from profiles/ (separate rocprofv3 passes of this command), null if absent; rocprof_avg_launch_us = the family's average kernel "
-                        "duration in the committed single-stream rocprofv3 summary (profiles/r02_d_*): avg_launch_us brackets each launch with a "
+                        "duration in the committed single-stream rocprofv3 summary (profiles/r02_f_*): avg_launch_us brackets each launch with a "
                         "HIP-event pair and so carries ~4 us of dispatch per launch on top of it; mfma_view / attn_*: 2MNK FLOPs per "
                         "contraction, 4*B*H*Tq*Tk*64 per attention forward (x2.5 backward, causal at T(T+1)/2); each product costs %d bf16 MFMAs in "
                         "%s mode; sustained MFMA peak = tools/mfma_peak.cpp on this chip" % (config.NSPLIT, a.precision)}
