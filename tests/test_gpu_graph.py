@@ -135,3 +135,40 @@ def test_randperm_is_uniform():
         counts[torch.arange(n), p] += 1
     exp = draws / n
     assert float((counts - exp).abs().max()) < 6 * (exp ** 0.5), float((counts - exp).abs().max())
+
+
+def test_graph_replay_with_alternating_input_shapes():
+    """Batches of two different padded shapes alternate (A A A A B B B B A A A A): each shape keeps its own capture AND the
+    static input buffers that capture was recorded with (a capture replayed against re-allocated buffers would read freed
+    memory: token ids and lengths of garbage).  Frozen parameters (lr ~ 1e-7), RNG sites off: every loss equals the eager run's."""
+    from unast_amd import train, utils
+    from unast_amd.engine import join_streams
+    from unast_amd.graphed import GraphedTrainStep
+    shapes = [(4, 28, 96)] * 4 + [(3, 20, 64)] * 4 + [(4, 28, 96)] * 4
+    out = []
+    for graphed in (True, False):
+        utils.set_deterministic(True)
+        try:
+            args, model, opt, sched = build(2, 1e-7)
+            losses = defaultdict(list)
+            stepper = GraphedTrainStep(model, opt, None, args) if graphed else None
+            for i, (B, Tt, Tm) in enumerate(shapes):
+                b = batches_for(i, B, Tt, Tm)
+                if graphed:
+                    stepper(losses, b, i)
+                else:
+                    train.train_step(losses, model, opt, None, b, i, args, defer_d_phase=True)
+            if graphed:
+                assert len(stepper.graphs) == 2 and len(stepper.static_by_sig) == 2
+                stepper.flush(losses)
+            join_streams(); torch.cuda.synchronize()
+        finally:
+            utils.set_deterministic(False)
+        out.append({k: [float(x) for x in v] for k, v in losses.items()})
+    g, e = out
+    for k in e:
+        assert len(g[k]) == len(e[k]), k
+        for x, y in zip(g[k], e[k]):
+            assert abs(x - y) < 2e-5 * max(1.0, abs(y)), (k, x, y)
+    assert all(np.isfinite(v).all() for v in g.values())
+

@@ -55,7 +55,8 @@ class GraphedTrainStep:
         if not isinstance(optimizer, T.FusedAdamW):
             raise TypeError("GraphedTrainStep needs the FusedAdamW built by train.initialize_model")
         self.model, self.opt, self.sched, self.args = model, optimizer, scheduler, args
-        self.static = None            # {"unsup": [...], "sup": [...], "disc": [...]} of 4-tuples of device tensors
+        self.static = None            # {"unsup": [...], "sup": [...], "disc": [...]} of 4-tuples of device tensors (of the current signature)
+        self.static_by_sig = {}       # a capture reads the buffers it was recorded with: one set per input signature, kept with its graph
         self.sig = None
         self.graphs = {}              # signature -> _Captured
         self.pending_lr = None        # learning rate of the D phase that has not run yet (None: nothing pending)
@@ -76,13 +77,16 @@ class GraphedTrainStep:
     def _load(self, batches, keys):
         """Copies the batches into the static input buffers (device-to-device or host-to-device on the current stream)."""
         dev = T._dev()
-        if self.static is None or self.sig != self._signature(batches):
+        sig = self._signature(batches)
+        if self.static is None or self.sig != sig:
             assert self.pending_lr is None
-            self.sig = self._signature(batches)
-            self.static = {}
-            a = self.args
-            for k, n in (("unsup", a.ae_steps), ("sup", a.sp_steps), ("disc", a.d_steps if a.use_discriminator else 0)):
-                self.static[k] = [tuple(torch.empty(t.shape, dtype=t.dtype, device=dev) for t in batches[k][i]) for i in range(n)]
+            self.sig = sig
+            self.static = self.static_by_sig.get(sig)
+            if self.static is None:
+                self.static = self.static_by_sig[sig] = {}
+                a = self.args
+                for k, n in (("unsup", a.ae_steps), ("sup", a.sp_steps), ("disc", a.d_steps if a.use_discriminator else 0)):
+                    self.static[k] = [tuple(torch.empty(t.shape, dtype=t.dtype, device=dev) for t in batches[k][i]) for i in range(n)]
         for k in keys:
             for dst, src in zip(self.static[k], batches[k]):
                 for d, s in zip(dst, src):
@@ -171,10 +175,15 @@ class GraphedTrainStep:
 
     def _capture(self, sig):
         from .inference import _capture
-        if len(self.graphs) >= MAX_GRAPHS:
-            self.graphs.pop(next(iter(self.graphs)))
         join_streams()
         torch.cuda.synchronize()
+        while len(self.graphs) >= MAX_GRAPHS:             # evict the oldest capture (nothing of it is in flight after the synchronize)
+            old = next(iter(self.graphs))
+            self._drop(old)
+        for old in [k for k in self.static_by_sig if k not in self.graphs and k != sig]:
+            if len(self.static_by_sig) <= MAX_GRAPHS:
+                break
+            del self.static_by_sig[old]
         rec = _Captured()
         cap_losses = defaultdict(list)
         self.opt.captured_ranges = []
@@ -209,6 +218,16 @@ class GraphedTrainStep:
         rec.ranges = list(self.opt.captured_ranges)
         self.graphs[sig] = rec
         return rec
+
+    def _drop(self, sig):
+        rec = self.graphs.pop(sig)
+        if rec.plan:
+            from ._lib import lib
+            lib().unast_graph_plan_destroy(rec.plan)
+            rec.plan = 0
+        if sig != self.sig:
+            self.static_by_sig.pop(sig, None)
+        self.warmed.discard(sig)
 
     def _replay(self, rec, losses, lr_now):
         hyper = {}
