@@ -172,3 +172,12 @@ def test_graph_replay_with_alternating_input_shapes():
             assert abs(x - y) < 2e-5 * max(1.0, abs(y)), (k, x, y)
     assert all(np.isfinite(v).all() for v in g.values())
 
+
+def test_odd_shapes_and_step_layouts_eager_vs_replay():
+    """tools/stress_shapes.py: tiny and odd lengths, batch 1, more input signatures than cached captures (eviction), accumulation
+    over two sub-steps of each kind, generator only -- finite losses and eager == replay at frozen parameters, in a fresh process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_shapes.py")], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert out.returncode == 0 and b"stress ok" in out.stdout, out.stdout.decode()[-3000:]
+
