@@ -51,6 +51,36 @@ def test_train_loop_through_captured_graphs(tmp_path):
         assert torch.isfinite(p).all()
 
 
+def test_train_loop_through_captured_graphs_with_changing_batch_shapes(tmp_path):
+    """The same loop when the padded batch shape changes from step to step (what a length-sorted loader produces): three shapes
+    cycle, sub-steps of one outer step may differ too.  The stepper keeps one capture and one set of input buffers per shape,
+    runs the pending discriminator phase before it switches -- losses stay finite, every key gets all its entries, it learns."""
+    from unast_amd import train, utils
+    from unast_amd.portable import synth_batch
+    train.DEVICE = D
+    utils.set_deterministic(False)
+    args = small_args(checkpoint_path=str(tmp_path / "ckpt"), epochs=3, epoch_steps=8, use_hip_graphs=True)
+
+    class Cycling:
+        shapes = [(12, 32), (9, 24), (12, 32), (15, 40)]
+
+        def __init__(self):
+            self.n = 0
+
+        def _next(self):
+            self.n += 1
+            tt, tm = self.shapes[(self.n // 3) % len(self.shapes)]
+            return tuple(torch.from_numpy(x) for x in synth_batch(args.train_batch_size, tt, tm, seed=self.n, ragged=True))
+        get_supervised_batch = get_unsupervised_batch = get_discriminator_batch = _next
+
+    model, hist = train.train(args, batch_getter=Cycling())
+    assert len(hist) == 3 and set(hist[0]) == {"t_ae", "s_ae", "d_ae", "asr_", "tts_", "sp_d", "d"}
+    assert all(v == v and abs(v) < 1e6 for h in hist for v in h.values())
+    assert hist[-1]["s_ae"] < hist[0]["s_ae"] and hist[-1]["tts_"] < hist[0]["tts_"]
+    for p in model.parameters():
+        assert torch.isfinite(p).all()
+
+
 def test_checkpoint_roundtrip_and_torch_adamw_format(tmp_path):
     from collections import defaultdict
     from unast_amd import train, utils
