@@ -198,6 +198,25 @@ st.touched = {"disc"}
 n = ddp.finish(st, [(960, 1024)])
 assert n == 1 and torch.allclose(st.grad, exp)
 assert not ddp._State.armed and ddp._State.issued == []
+# --- a cross-model sub-step as the last one (sp_steps = 0): forward order text_enc, speech_dec, speech_enc, text_dec; autograd
+# runs the speech ENCODER's backward before the speech DECODER's, and the decoder still adds speech_m.prenet.* gradients into the
+# encoder's bucket: that bucket must not travel before the decoder's backward has been enqueued ---
+st.grad = torch.arange(1024, dtype=torch.float32) * (rank + 1)
+st.touched = {"gen"}
+ddp._State.log = []
+ddp.arm()
+for b in ("text_enc", "speech_dec", "speech_enc", "text_dec"):
+    ddp.segment_forward(b)
+ddp.segment_backward("text_dec", st)
+ddp.segment_backward("speech_enc", st)                   # its own backward is done, the decoder's (same prenet) is not
+assert [l[0] for l in ddp._State.log] == ["text_dec"], ddp._State.log
+assert torch.equal(st.grad[512:704], own[512:704])
+ddp.segment_backward("speech_dec", st)                   # now both buckets of the speech side are final
+assert [l[0] for l in ddp._State.log] == ["text_dec", "speech_dec", "speech_enc"], ddp._State.log
+ddp.segment_backward("text_enc", st)
+assert [l[0] for l in ddp._State.log] == ["text_dec", "speech_dec", "speech_enc", "text_enc"]
+n = ddp.finish(st, [(0, 960)])
+assert n == 0 and torch.allclose(st.grad[:960], exp[:960]) and torch.equal(st.grad[960:], own[960:])
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """

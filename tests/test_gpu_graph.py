@@ -124,6 +124,30 @@ def test_graph_replays_draw_fresh_masks_and_permutations():
         ops.rng_epoch_counter().zero_()
 
 
+def test_masks_of_neighbouring_sites_do_not_repeat_across_epochs():
+    """Sites of one call use consecutive stream ids and replays consecutive epochs: the mask of site s at epoch e + 1 must not be
+    the mask site s + 1 drew at epoch e (it was, while stream id and epoch were added under one hash), and the same
+    (site, epoch) must reproduce."""
+    from unast_amd import ops
+    x = torch.ones(4096, 80, device=D)
+
+    def mask(stream_id, epoch):
+        ops.set_step_state(epoch, {})
+        y = torch.empty_like(x)
+        ops.rowmask(x, y, 0.3, 77, stream_id)
+        return y[:, 0].clone()
+    try:
+        a = mask(4, 5)
+        assert torch.equal(a, mask(4, 5))
+        assert 0.25 < 1.0 - float(a.mean()) < 0.35
+        for s, e in ((3, 6), (5, 4), (4, 6), (5, 5)):
+            b = mask(s, e)
+            agree = float((a == b).float().mean())                  # independent masks agree on 0.7^2 + 0.3^2 = 0.58 of the rows
+            assert 0.52 < agree < 0.64, (s, e, agree)
+    finally:
+        ops.rng_epoch_counter().zero_()
+
+
 def test_randperm_is_uniform():
     """Every position receives every value about equally often (4096 draws of a 16-permutation)."""
     from unast_amd import ops

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) { dk[dt][ks] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][ks] = dk[dt][ks]; }
 
-    const uint32_t rbase = pcg_hash(p.stream + rng_epoch() + pcg_hash(p.seed));      // rng_row_key(seed, stream, row) = pcg(row + rbase)
+    const uint32_t rbase = rng_stream_base(p.seed, p.stream);      // rng_row_key(seed, stream, row) = pcg(row + rbase)
     const bool block_live = kblk < klen;                    // all keys of the block masked -> gradients are zero
     const int qt_begin = p.causal ? (kblk / 32) : 0;
     const int qt_end = block_live ? (p.Tq + 31) / 32 : qt_begin;

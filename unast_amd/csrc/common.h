@@ -44,8 +44,13 @@ __device__ __forceinline__ uint32_t rng_epoch() {
     const uint32_t* p = g_unast_rng_epoch;
     return p ? *p : 0u;
 }
+// The epoch is hashed on its own before the stream id is added: with `stream + epoch` under one hash, site s at replay e + 1 drew
+// exactly the mask site s + 1 had drawn at replay e (sites of a call use consecutive stream ids, replays consecutive epochs).
+__device__ __forceinline__ uint32_t rng_stream_base(uint32_t seed, uint32_t stream) {
+    return pcg_hash(stream + pcg_hash(rng_epoch() + pcg_hash(seed)));
+}
 __device__ __forceinline__ uint32_t rng_row_key(uint32_t seed, uint32_t stream, uint32_t row) {
-    return pcg_hash(row + pcg_hash(stream + rng_epoch() + pcg_hash(seed)));
+    return pcg_hash(row + rng_stream_base(seed, stream));
 }
 #define UNAST_DEFINE_RNG_EPOCH_SETTER(tu)                                                                                 \
     extern "C" int unast_tu_##tu##_set_rng_epoch(const unsigned int* p) {                                                 \

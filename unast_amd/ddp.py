@@ -112,9 +112,25 @@ def disarm():
     _State.armed = False
 
 
+def _buckets_of(bucket):
+    """A public call names the bucket its own parameters form; the decoders ALSO accumulate into parameters that live in their
+    modality's encoder bucket (speech_decode runs speech_m.prenet.*, text_decode the embedding table text_m.prenet.embed), so
+    they count as users of that bucket too: it is final only when the encoder's AND the decoder's backward have been enqueued,
+    whatever order autograd runs them in (a cross-model sub-step runs an encoder's backward before its modality's decoder's)."""
+    if bucket is None:
+        return ()
+    if isinstance(bucket, (tuple, list)):
+        return tuple(bucket)
+    return (bucket,) + _ALSO_WRITES.get(bucket, ())
+
+
+_ALSO_WRITES = {"text_dec": ("text_enc",), "speech_dec": ("speech_enc",)}
+
+
 def segment_forward(bucket):
-    if _State.armed and bucket is not None:
-        _State.fwd_count[bucket] = _State.fwd_count.get(bucket, 0) + 1
+    if _State.armed:
+        for bk in _buckets_of(bucket):
+            _State.fwd_count[bk] = _State.fwd_count.get(bk, 0) + 1
 
 
 def segment_backward(bucket, store):
@@ -122,13 +138,14 @@ def segment_backward(bucket, store):
     companion streams)."""
     if not _State.armed or bucket is None:
         return
-    _State.bwd_count[bucket] = _State.bwd_count.get(bucket, 0) + 1
-    if _State.bwd_count[bucket] < _State.fwd_count.get(bucket, 0):
-        return
-    rng = bucket_ranges(store).get(bucket)
-    if rng is None or "gen" not in store.touched or any(r == rng for r in _State.issued):
-        return
-    _issue(store, bucket, rng, overlap=True)
+    for bk in _buckets_of(bucket):
+        _State.bwd_count[bk] = _State.bwd_count.get(bk, 0) + 1
+        if _State.bwd_count[bk] < _State.fwd_count.get(bk, 0):
+            continue
+        rng = bucket_ranges(store).get(bk)
+        if rng is None or "gen" not in store.touched or any(r == rng for r in _State.issued):
+            continue
+        _issue(store, bk, rng, overlap=True)
 
 
 def _issue(store, label, rng, overlap):
