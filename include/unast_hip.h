@@ -260,6 +260,38 @@ int unast_split_f32(const float* src, float* dst, int64_t n, hipStream_t stream)
  * memory {src offset, dst offset, rows, cols, row0, col0} per 64 x 64 tile (float offsets from the bases; cols % 4 == 0, source
  * offsets multiples of 4). */
 int unast_transpose_split(const float* src_base, float* dst_base, const int* tiles_dev, int ntiles, hipStream_t stream);
+
+/* Row-panel GEMM for the K <= 256 contractions of the transformer layers, C[M,N] = epi(A[M,K] W[N,K]^T): in-projections,
+ * out-projections, linear1, cross-attention projections and (with W^T planes) their input gradients -- the nn.Linear /
+ * MultiheadAttention projections inside torch.nn.TransformerEncoderLayer / DecoderLayer (src/module.py:273-274, 286-287) and the
+ * autograd of the same call sites.  A workgroup keeps a 128- or 64-row panel of A in registers (split into hi / lo bf16 once) and
+ * streams the weights through LDS by LDS-DMA from TILED BF16 PLANES written by unast_retile_weights.
+ * w_planes: hi plane of W (lo plane at + plane_bytes); N and K may be smaller than the planes' padded extents.
+ * Epilogue: x = acc + bias[n] -> relu if act == 1 -> dropout(drop_p; mask = f(seed, stream_id, m, n) as unast_gemm) ->
+ *           gate (G > 0 ? x * gate_scale : 0) -> + R[m,n]; out_split as unast_gemm.
+ * ln_gamma != NULL (needs N = 256): the post-LN sub-layer is finished here -- C receives z = R + dropout(acc + bias),
+ *           Y = LayerNorm(z) * gamma + beta (eps), mean / rstd [M] the row statistics the LayerNorm backward reads
+ *           (replaces unast_layernorm_fwd behind the out-projection / linear2).
+ * gate_bits (may be NULL; needs N % 64 == 0): one keep bit per element of an [M,N] activation, ceil128(M) * N / 8 bytes (whole row panels) --
+ *           word ((m / 16) * (N / 16) + n / 16) * 4 + r of 64 bits holds at bit 4 * ... 16 * ((n % 16) / 4) + m % 16 whether element
+ *           (m, 16 (n / 16) + 4 ((n % 16) / 4) + r) is > 0.  With act == 1 and dropout (linear1: relu -> dropout, src/module.py:273-274
+ *           -> torch TransformerEncoderLayer) the launch WRITES them next to C; with act == 0 and no bias (the input gradient through
+ *           linear2) it READS them as the gate x = bit ? x * gate_scale : 0 -- relu' and the dropout mask of the hidden activation
+ *           without re-reading it.
+ * rows_per_wg: 128 (8 waves x 32 rows), 1128 (128 rows as 16 waves x 16 rows), 64 or 0 (library picks). */
+int unast_panel_gemm(const float* A, int lda, const void* w_planes, int64_t plane_bytes, float* C, int ldc, int M, int N, int K,
+                     const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale, int act,
+                     float drop_p, unsigned int seed, unsigned int stream_id, int out_split,
+                     const float* ln_gamma, const float* ln_beta, float* Y, int ldy, float* mean, float* rstd, float eps,
+                     void* gate_bits, int rows_per_wg, hipStream_t stream);
+/* The weights of a parameter region once more as tiled bf16 planes for unast_panel_gemm, refreshed after each optimizer step.
+ * descs_dev: ndesc records of 48 bytes in device memory, one per 64 x 64 block of a destination matrix Wd[n][k]:
+ *   int32 {src offset (floats from src_base), src row stride, transposed, N, K, n0, k0, ksteps = ceil(K / 32)},
+ *   int64 {dst offset of the hi plane (bytes from dst_base), plane bytes = ceil64(N) * ksteps * 64}.
+ * transposed = 0: Wd[n][k] = src[n * ld + k] (forward operand); 1: Wd[n][k] = src[k * ld + n] (input-gradient operand W^T).
+ * Plane layout: 1-KB sub-tiles of 16 n x 32 k at ((n / 16) * ksteps + k / 32) * 1024, inside a sub-tile 16-byte units
+ * [(k % 32) / 8][n % 16] of 8 consecutive k; hi = RNE_bf16(x), lo = RNE_bf16(x - hi); padding is zero. */
+int unast_retile_weights(const float* src_base, void* dst_base, const void* descs_dev, int ndesc, hipStream_t stream);
 /* Writes n <= 16 32-bit words (read from HOST memory at call time, passed by value in the kernel arguments) to device memory:
  * refreshes the block a captured step reads (RNG epoch of unast_set_rng_epoch, dev_hyper triples of unast_adamw) once per
  * replay; stands where the reference's Python passes lr / step to torch.optim (src/train.py:361, 654-655). */

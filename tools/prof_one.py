@@ -26,4 +26,12 @@ elif which == "attn_bwd":
     for _ in range(10):
         ops.attn_bwd(qkv[:, :E], qkv[:, E:2*E], qkv[:, 2*E:], O, dO, LSE, delta, dqkv[:, :E], dqkv[:, E:2*E], dqkv[:, 2*E:], lens, B, H, T, T, False,
                      drop_p=0.1, seed=1, stream_id=1)
+elif which in ("panel_ffn1", "tile_ffn1"):
+    from unast_amd.planes import Planes
+    M, N, K = 25600, 1024, 256
+    x = torch.randn(M, K, device=D); W = torch.randn(N, K, device=D) * 0.05; b = torch.randn(N, device=D); y = torch.empty(M, N, device=D)
+    pl = Planes([W])
+    for _ in range(10):
+        if which == "panel_ffn1": ops.panel_gemm(x, pl.ref(0), y, N, bias=b, act=1, drop_p=0.1, seed=5, stream_id=3, rows_per_wg=128)
+        else: ops.linear_fwd(x, W, b, y, act=1, drop_p=0.1, seed=5, stream_id=3)
 torch.cuda.synchronize()

@@ -65,3 +65,17 @@ ATTN_PRESPLIT = os.environ.get("UNAST_ATTN_PRESPLIT", "1") != "0"
 # BatchNorm batch statistics of the conv stacks taken in the conv GEMM's epilogue (unast_gemm colstats) instead of by a column-sum
 # pass over the conv output.  0 = the separate pass (A/B).
 CONV_BN_STATS = os.environ.get("UNAST_CONV_BN_STATS", "1") != "0"
+
+# Row-panel GEMM (csrc/panel.hip) for K <= 256 contractions over at least PANEL_MIN_ROWS rows: the activation panel stays in registers,
+# the weights stream through LDS by LDS-DMA from tiled bf16 planes kept next to the flat parameter store (engine.FlatStore).  Measured on
+# MI355X against the tile GEMM at M = 25 600 (tools/bench_panel.py): linear1 51-54 vs 67-70 us, in-projection 42-45 vs 47-52, out-projection
+# 17.6 vs 21, K/V projection 29 vs 36, prenet fc1 11 vs 14.7; at M = 5 760 (text side) the tile kernel is faster.  0 = tile GEMM everywhere.
+PANEL_GEMM = os.environ.get("UNAST_PANEL", "1") != "0"
+PANEL_MIN_ROWS = int(os.environ.get("UNAST_PANEL_MIN_ROWS", "16384"))
+# 1128 = 128-row panels as 16 waves x 16 rows (4 waves / SIMD); 128 = 8 waves x 32 rows; 64 = 8 waves x 16 rows
+PANEL_ROWS = int(os.environ.get("UNAST_PANEL_ROWS", "1128"))
+# LayerNorm in the epilogue of the out-projection GEMMs (post-LN sub-layers): z, y, mean, rstd come out of one launch.
+PANEL_LN = os.environ.get("UNAST_PANEL_LN", "1") != "0"
+# linear1 writes one keep bit per hidden element (relu > 0 and not dropped); linear2's input-gradient GEMM gates with those bits
+# (scalar loads) instead of re-reading the 105 MB hidden activation.
+PANEL_GATE_BITS = os.environ.get("UNAST_PANEL_GATE_BITS", "1") != "0"

@@ -33,8 +33,9 @@ extern "C" int unast_tu_gemm_set_rng_epoch(const unsigned int*);
 extern "C" int unast_tu_loss_set_rng_epoch(const unsigned int*);
 extern "C" int unast_tu_lstm_set_rng_epoch(const unsigned int*);
 extern "C" int unast_tu_norm_set_rng_epoch(const unsigned int*);
+extern "C" int unast_tu_panel_set_rng_epoch(const unsigned int*);
 extern "C" int unast_set_rng_epoch(const unsigned int* counter) {
     int rc = unast_tu_attention_set_rng_epoch(counter) | unast_tu_decode_set_rng_epoch(counter) | unast_tu_elementwise_set_rng_epoch(counter) | unast_tu_gemm_set_rng_epoch(counter) |
-             unast_tu_loss_set_rng_epoch(counter) | unast_tu_lstm_set_rng_epoch(counter) | unast_tu_norm_set_rng_epoch(counter);
+             unast_tu_loss_set_rng_epoch(counter) | unast_tu_lstm_set_rng_epoch(counter) | unast_tu_norm_set_rng_epoch(counter) | unast_tu_panel_set_rng_epoch(counter);
     return rc ? unast_set_error(UNAST_ERR_LAUNCH, "unast_set_rng_epoch: hipMemcpyToSymbol failed") : UNAST_OK;
 }

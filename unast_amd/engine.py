@@ -383,7 +383,8 @@ class FlatStore:
         self.flat_split = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self._split_ver = None
         self._build_transposed()
-        ops.register_weight_span(self.flat.data_ptr(), self.total * 4, self.flat_split.data_ptr(), self.dgrad_T)
+        self._build_planes()
+        ops.register_weight_span(self.flat.data_ptr(), self.total * 4, self.flat_split.data_ptr(), self.dgrad_T, self.planes_of)
         self.dummy = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)   # forces autograd to call our backward
         self.touched = set()           # regions that received gradients since the last zero_grad
         self.grads_exposed = False
@@ -461,6 +462,79 @@ class FlatStore:
         self._tcache[key] = res
         return res
 
+    # tiled bf16 planes (B operand of the row-panel GEMM, csrc/panel.hip) ------------------------------------------------
+    def _build_planes(self):
+        """Every 2-D weight W [rows, K] with K <= 256 gets tiled hi / lo planes of itself (forward operand) and, when rows <= 256,
+        of W^T (the operand of its input-gradient GEMM dX = dY W); combined operands (the [81, 256] head, the LSTM's [2 * 4H, Din]
+        input projections) and the q rows of the cross-attention in-projections likewise.  `refresh_planes` re-tiles a region with
+        one launch (unast_retile_weights) after every optimizer step and whenever sync_split() sees parameters written through torch."""
+        from . import config, planes
+        self._pmats, self._pcache, self.planes_buf, self._pdescs = [], {}, None, {}
+        if not config.PANEL_GEMM:
+            return
+        cands = []                                   # (flat offset, source row stride, rows, cols, region)
+        for n, p in self.params.items():
+            if p.dim() == 2 and not n.endswith(".conv.weight"):
+                cands.append((self.offsets[n], p.shape[1], p.shape[0], p.shape[1], _region_of(n)))
+                if n.endswith("multihead_attn.in_proj_weight") and p.shape[0] == 3 * p.shape[1]:      # q rows: their own W^T
+                    cands.append((self.offsets[n], p.shape[1], p.shape[1], p.shape[1], _region_of(n)))
+        P = self.params
+        if "speech_m.postnet.linear_project.weight" in P:
+            a, b = P["speech_m.postnet.linear_project.weight"], P["speech_m.postnet.stop_linear.weight"]
+            cands.append((self.offsets["speech_m.postnet.linear_project.weight"], a.shape[1], a.shape[0] + b.shape[0], a.shape[1], "gen"))
+        for n, p in P.items():
+            if n.startswith("discriminator.rnn.rnn.weight_ih_l") and not n.endswith("_reverse") and (n + "_reverse") in P:
+                cands.append((self.offsets[n], p.shape[1], 2 * p.shape[0], p.shape[1], "disc"))
+        mats, seen = [], set()
+        for off, ld, rows, cols, region in cands:
+            if planes.eligible(rows, cols) and (off, rows, cols, 0) not in seen:        # Wd[n = rows][k = cols]
+                seen.add((off, rows, cols, 0)); mats.append((off, ld, 0, rows, cols, region))
+            if planes.eligible(cols, rows) and (off, rows, cols, 1) not in seen:        # Wd[n = cols][k = rows] = W^T
+                seen.add((off, rows, cols, 1)); mats.append((off, ld, 1, cols, rows, region))
+        if not mats:
+            return
+        descs, placed, total = planes.plan([m[:5] for m in mats])
+        self.planes_buf = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        self._pmats = [(m[0], m[1], m[2], m[3], m[4], m[5]) + pl for m, pl in zip(mats, placed)]      # + (dst_off, plane_bytes, ksteps)
+        import numpy as np
+        regions = np.repeat([m[5] for m in mats], [((m[3] + 63) // 64) * ((((m[4] + 31) // 32) * 32 + 63) // 64) for m in mats])
+        for region in ("gen", "disc", "disc_unused"):
+            sel = descs[regions == region]
+            if len(sel):
+                self._pdescs[region] = (planes.descs_to_device(sel, self.device), len(sel))
+
+    def refresh_planes(self, regions=None):
+        for region, (descs, n) in self._pdescs.items():
+            if regions is None or region in regions:
+                ops.retile_weights(self.flat, self.planes_buf, descs, n)
+
+    def planes_of(self, W, transposed=False):
+        """(hi-plane pointer, plane bytes) of the tiled planes of the stored weight view W [N, K] (transposed: of W^T), or None."""
+        if self.planes_buf is None or W.dim() != 2 or W.stride(1) != 1:
+            return None
+        key = (W.data_ptr(), W.shape[0], W.shape[1], W.stride(0), transposed)
+        hit = self._pcache.get(key, 0)
+        if hit != 0:
+            return hit
+        res = None
+        pos = (W.data_ptr() - self.flat.data_ptr()) // 4
+        rows, cols = W.shape
+        for off, ld, tr, N, K, region, dst, pb, ksteps in self._pmats:
+            if W.stride(0) != ld or tr != int(transposed):
+                continue
+            if not transposed:
+                # rows [row0, row0 + rows) of a stored [N, K] operand: the planes are cut in 16-row tiles, a 64-row boundary keeps groups whole
+                if cols == K and off <= pos < off + N * K and (pos - off) % K == 0:
+                    row0 = (pos - off) // K
+                    if row0 % 64 == 0 and row0 + rows <= N:
+                        res = (self.planes_buf.data_ptr() + dst + (row0 // 16) * ksteps * 1024, pb)
+                        break
+            elif pos == off and cols == N and rows == K:
+                res = (self.planes_buf.data_ptr() + dst, pb)
+                break
+        self._pcache[key] = res
+        return res
+
     def sync_split(self):
         """Re-split the weights if any parameter was written through torch since the last look (load_state_dict, manual
         edits: they bump the parameter's version counter; the AdamW kernel updates both copies itself)."""
@@ -470,6 +544,7 @@ class FlatStore:
         if ver != self._split_ver:
             ops.split_f32(self.flat, self.flat_split)
             self.refresh_T()
+            self.refresh_planes()
             self._split_ver = ver
 
     # combined operands ---------------------------------------------------------------------------------------

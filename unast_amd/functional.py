@@ -87,8 +87,9 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
     LSE = _empty(B, H, Tq, like=x.v)
     ops.attn_fwd(Q, K, V, O, LSE, lens_k, B, H, Tq, Tk, causal, drop_p=p, seed=cx.seed, stream_id=s_attn, qkv_split=ps)
     z = _empty(Nq, E, like=x.v)
-    ops.linear_fwd(O, Wo, bo, z, drop_p=p, seed=cx.seed, stream_id=s_out, R=x.v)          # z = x + drop(O Wo^T + bo)
-    y, mean, rstd = _layernorm(cx, tape, z, pre_norm, None)
+    y, mean, rstd = _empty(Nq, E, like=x.v), _empty(Nq, like=x.v), _empty(Nq, like=x.v)
+    # z = x + drop(O Wo^T + bo), y = LayerNorm(z): one launch where the row-panel GEMM serves the shape, GEMM + LayerNorm otherwise
+    ops.linear_fwd(O, Wo, bo, z, drop_p=p, seed=cx.seed, stream_id=s_out, R=x.v, ln=(cx.P[pre_norm + "weight"], cx.P[pre_norm + "bias"], y, mean, rstd, LN_EPS))
     out = Var(y)
     if tape is not None:
         seed = cx.seed
@@ -147,10 +148,14 @@ def ffn_sublayer(cx, tape, x, pre, pre_norm, drop):
     p = cx.p(drop)
     s1, s2 = cx.stream(), cx.stream()
     h = _empty(N, F, like=x.v)
-    ops.linear_fwd(x.v, W1, b1, h, act=1, drop_p=p, seed=cx.seed, stream_id=s1)
+    # keep bits of h (relu > 0 and not dropped) for the backward's gate, when both GEMMs that touch them run on the row-panel kernel
+    bits = None
+    if tape is not None and config.PANEL_GATE_BITS and F % 64 == 0 and F <= 1024 and ops.panel_serves(N, E, W1) and ops.panel_serves(N, E, W2, transposed=True):
+        bits = torch.empty(ops.gate_bits_bytes(N, F), dtype=torch.uint8, device=x.v.device)
+    ops.linear_fwd(x.v, W1, b1, h, act=1, drop_p=p, seed=cx.seed, stream_id=s1, gate_bits=bits)
     z = _empty(N, E, like=x.v)
-    ops.linear_fwd(h, W2, b2, z, drop_p=p, seed=cx.seed, stream_id=s2, R=x.v)
-    y, mean, rstd = _layernorm(cx, tape, z, pre_norm, None)
+    y, mean, rstd = _empty(N, E, like=x.v), _empty(N, like=x.v), _empty(N, like=x.v)
+    ops.linear_fwd(h, W2, b2, z, drop_p=p, seed=cx.seed, stream_id=s2, R=x.v, ln=(cx.P[pre_norm + "weight"], cx.P[pre_norm + "bias"], y, mean, rstd, LN_EPS))
     out = Var(y)
     if tape is not None:
         seed = cx.seed
@@ -172,7 +177,11 @@ def ffn_sublayer(cx, tape, x, pre, pre_norm, drop):
             if g2 is not None:
                 ops.linear_wgrad(da, h, g2, db=st.g(pre + "linear2.bias"))
             du = _empty(N, F, like=z)
-            ops.linear_dgrad(da, W2, du, G=h, gate_scale=(1.0 / (1.0 - p) if p > 0 else 1.0))      # relu' and dropout mask from h > 0
+            gsc = 1.0 / (1.0 - p) if p > 0 else 1.0
+            if bits is not None:
+                ops.linear_dgrad(da, W2, du, gate_bits=bits, gate_scale=gsc)                      # relu' and dropout mask from the keep bits
+            else:
+                ops.linear_dgrad(da, W2, du, G=h, gate_scale=gsc)                                 # ... from h > 0
             g1 = st.g(pre + "linear1.weight")
             if g1 is not None:
                 ops.linear_wgrad(du, x.v, g1, db=st.g(pre + "linear1.bias"))

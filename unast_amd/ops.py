@@ -40,17 +40,26 @@ def _f32(t, name):
 _WEIGHT_SPANS = []
 
 
-def register_weight_span(base_ptr, nbytes, split_ptr, transposed_lookup=None):
+def register_weight_span(base_ptr, nbytes, split_ptr, transposed_lookup=None, planes_lookup=None):
     _WEIGHT_SPANS[:] = [s for s in _WEIGHT_SPANS if s[0] != base_ptr]
-    _WEIGHT_SPANS.append((base_ptr, nbytes, split_ptr, transposed_lookup))
+    _WEIGHT_SPANS.append((base_ptr, nbytes, split_ptr, transposed_lookup, planes_lookup))
 
 
 def unregister_weight_span(base_ptr):
     _WEIGHT_SPANS[:] = [s for s in _WEIGHT_SPANS if s[0] != base_ptr]
 
 
+def _weight_planes(W, transposed=False):
+    """(hi-plane pointer, plane bytes) of the tiled bf16 planes of a stored weight view (engine.FlatStore.planes_of), or None."""
+    ptr = W.data_ptr()
+    for base, nbytes, split, _, lookup in _WEIGHT_SPANS:
+        if lookup is not None and base <= ptr < base + nbytes:
+            return lookup(W, transposed)
+    return None
+
+
 def _presplit_ptr(ptr):
-    for base, nbytes, split, _ in _WEIGHT_SPANS:
+    for base, nbytes, split, _, _p in _WEIGHT_SPANS:
         if base <= ptr < base + nbytes:
             return split + (ptr - base)
     return 0
@@ -59,7 +68,7 @@ def _presplit_ptr(ptr):
 def _transposed_weight(W):
     """(pointer, row stride) of W^T in the pre-split format if W is a stored weight that has one (engine.FlatStore.dgrad_T)."""
     ptr = W.data_ptr()
-    for base, nbytes, split, lookup in _WEIGHT_SPANS:
+    for base, nbytes, split, lookup, _p in _WEIGHT_SPANS:
         if lookup is not None and base <= ptr < base + nbytes:
             return lookup(W)
     return None
@@ -107,19 +116,61 @@ def _splitk_for(M, N, K):
     return max(1, min(want, ksteps // SPLITK_MIN_KSTEPS))
 
 
-def linear_fwd(x2d, W, bias, out, act=0, drop_p=0.0, seed=0, stream_id=0, R=None, out_split=False):
-    """out[M,N] = epi(x2d[M,K] @ W[N,K]^T + bias)."""
+def _panel_ok(M, K, *tensors):
+    if not (config.PANEL_GEMM and config.NSPLIT == 3 and M >= config.PANEL_MIN_ROWS and 4 <= K <= 256 and K % 4 == 0):
+        return False
+    for t in tensors:
+        if t is not None and (t.stride(-1) != 1 or t.data_ptr() % 16 or t.stride(0) % 4):
+            return False
+    return True
+
+
+def linear_fwd(x2d, W, bias, out, act=0, drop_p=0.0, seed=0, stream_id=0, R=None, out_split=False, ln=None, gate_bits=None):
+    """out[M,N] = epi(x2d[M,K] @ W[N,K]^T + bias).  ln = (gamma, beta, y, mean, rstd, eps): LayerNorm of `out` fused behind the GEMM when
+    the row-panel kernel serves the shape (returns True), a separate launch otherwise.  gate_bits: uint8 buffer that receives one
+    keep bit per output element (panel kernel only; see linear_dgrad)."""
     M, K = x2d.shape
     N = W.shape[0]
+    fuse_ln = ln is not None and config.PANEL_LN and N == 256 and not out_split and act == 0
+    if _panel_ok(M, K, x2d, out, R) and W.stride(1) == 1 and (R is None or fuse_ln):       # (a residual operand is served by the LayerNorm epilogue only)
+        wp = _weight_planes(W)
+        if wp is not None:
+            panel_gemm(x2d, wp, out, N, bias=bias, R=R, act=act, drop_p=drop_p, seed=seed, stream_id=stream_id, out_split=out_split,
+                       ln=ln if fuse_ln else None, rows_per_wg=config.PANEL_ROWS, gate_bits=gate_bits)
+            if ln is not None and not fuse_ln:
+                layernorm_fwd(out, ln[0], ln[1], ln[2], ln[3], ln[4], ln[5])
+            return out
+    if gate_bits is not None:
+        raise RuntimeError("linear_fwd: gate_bits needs the row-panel kernel (check ops.panel_serves first)")
     gemm(OP_KC, OP_KC, x2d, x2d.stride(0), W, W.stride(0), out, out.stride(0), M, N, K, bias=bias, act=act,
          drop_p=drop_p, seed=seed, stream_id=stream_id, R=R, ldr=(R.stride(0) if R is not None else 0), out_split=out_split)
+    if ln is not None:
+        layernorm_fwd(out, ln[0], ln[1], ln[2], ln[3], ln[4], ln[5])
     return out
 
 
-def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0, out_split=False):
-    """dx[M,K] = (dy2d[M,N] @ W[N,K]) gated by G>0, + R."""
+def gate_bits_bytes(M, N):
+    """Bytes of the keep-bit buffer of an [M, N] activation (unast_panel_gemm gate_bits): whole 128-row panels, one bit per element."""
+    return (M + 127) // 128 * 128 * ((N + 15) // 16 * 16) // 8
+
+
+def panel_serves(M, K, W, transposed=False):
+    """True when linear_fwd (transposed=False) / linear_dgrad (True) of this shape and stored weight run on the row-panel kernel."""
+    return _panel_ok(M, K) and W.stride(1) == 1 and _weight_planes(W, transposed) is not None
+
+
+def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0, out_split=False, gate_bits=None):
+    """dx[M,K] = (dy2d[M,N] @ W[N,K]) gated by G>0, + R.  gate_bits: the keep bits linear_fwd(..., gate_bits=) wrote for the [M,K]
+    activation that G would be (panel kernel only): the gate is read from them with scalar loads instead of from G."""
     M, N = dy2d.shape
     K = W.shape[1]
+    if N % 4 == 0 and R is None and G is None and _panel_ok(M, N, dy2d, dx) and beta == 0 and W.stride(1) == 1:
+        wp = _weight_planes(W, transposed=True)                # dX[M,K] = dY[M,N] (W^T)[K,N]^T: W^T planes, contraction over N
+        if wp is not None:
+            panel_gemm(dy2d, wp, dx, K, gate_scale=gate_scale, out_split=out_split, rows_per_wg=config.PANEL_ROWS, gate_bits=gate_bits)
+            return dx
+    if gate_bits is not None:
+        raise RuntimeError("linear_dgrad: gate_bits needs the row-panel kernel (check ops.panel_serves first)")
     Np = (N + 3) // 4 * 4          # dy2d is a view of a zero-padded buffer when N % 4 != 0 (logits 46->48, head 81->84, fc2 1->4)
     if Np != N and dy2d.stride(0) < Np:
         raise ValueError("linear_dgrad: dy must live in a zero-padded buffer with row stride >= %d" % Np)
@@ -289,6 +340,38 @@ def linear_wgrad(dy2d, x2d, dW, db=None):
         _BATCH.append((dy2d, x2d, dW, db))
         return dW
     return _linear_wgrad_now(dy2d, x2d, dW, db)
+
+
+_PANEL_TRACE = _os.environ.get("UNAST_PANEL_TRACE", "0") == "1"       # debugging: print and synchronise every row-panel launch
+
+
+def retile_weights(src_flat, dst_bytes, descs_dev, ndesc):
+    """Tiled bf16 planes (unast_amd.planes) of the matrices the descriptors name, from the fp32 buffer `src_flat`."""
+    check(lib().unast_retile_weights(_p(src_flat), _p(dst_bytes), _p(descs_dev), ndesc, _stream()), "unast_retile_weights")
+
+
+def panel_gemm(A, wplanes, C, N, bias=None, R=None, G=None, gate_scale=1.0, act=0, drop_p=0.0, seed=0, stream_id=0, out_split=False,
+               ln=None, rows_per_wg=0, K=None, gate_bits=None):
+    """C[M,N] = epi(A[M,K] W[N,K]^T) with W given as tiled planes `wplanes` = (hi-plane pointer, plane bytes).
+    ln = (gamma, beta, Y, mean, rstd, eps): LayerNorm epilogue (N = 256): C receives the pre-norm sum z, Y the normalised rows."""
+    M = A.shape[0]
+    K = A.shape[1] if K is None else K
+    g = b = Y = mean = rstd = None
+    eps, ldy = 0.0, 0
+    if ln is not None:
+        g, b, Y, mean, rstd, eps = ln
+        ldy = Y.stride(0)
+    if _PANEL_TRACE:
+        print("panel_gemm M=%d N=%d K=%d lda=%d ldc=%d bias=%s R=%s G=%s act=%d drop=%.2f split=%d ln=%s bits=%s rows=%d" % (
+            M, N, K, A.stride(0), C.stride(0), bias is not None, R is not None, G is not None, act, drop_p, out_split, ln is not None,
+            None if gate_bits is None else gate_bits.numel(), rows_per_wg), flush=True)
+    check(lib().unast_panel_gemm(_p(A), A.stride(0), wplanes[0], wplanes[1], _p(C), C.stride(0), M, N, K, _p(bias), _p(R),
+                                 R.stride(0) if R is not None else 0, _p(G), G.stride(0) if G is not None else 0, gate_scale, act,
+                                 drop_p, seed & 0xFFFFFFFF, stream_id, int(out_split), _p(g), _p(b), _p(Y), ldy, _p(mean), _p(rstd), eps,
+                                 _p(gate_bits), rows_per_wg, _stream()), "unast_panel_gemm")
+    if _PANEL_TRACE:
+        torch.cuda.synchronize()
+    return C
 
 
 def conv_fwd(x3d, Wp, bias, out, pad_left, colstats=None):

@@ -714,7 +714,9 @@ class FusedAdamW(torch.optim.Optimizer):
             ops.adamw(st.flat[a:b], st.grad[a:b], self._m[a:b], self._v[a:b], self._ss, float(max_norm), float(g["lr"]),
                       g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps[(a, b)], split_out=st.flat_split[a:b],
                       decoupled=self.decoupled)
-        st.refresh_T([r for r, ab in st.regions.items() if ab in ranges])      # W^T copies of what was just updated
+        upd = [r for r, ab in st.regions.items() if ab in ranges]
+        st.refresh_T(upd)                      # W^T copies of what was just updated
+        st.refresh_planes(upd)                 # ... and its tiled bf16 planes (row-panel GEMM)
 
     def replay_hyper(self, rng, lr):
         """Host side of one replay of a captured step for the range `rng`: advances its step count and returns
