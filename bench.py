@@ -259,7 +259,11 @@ def main():
         model.speech_m.infer_max_len = model.text_m.infer_max_len = a.cm_max_len
     losses = defaultdict(list)
 
-    can_graph = a.cm_steps == 0 and not dist_on and not a.profile_ops and a.time_every == 0
+    native = False
+    if dist_on:
+        from unast_amd import ddp
+        native = bool(ddp.native_comm())       # RCCL through the C ABI: the captured step then carries its gradient exchanges (csrc/comm.cpp)
+    can_graph = a.cm_steps == 0 and (not dist_on or native) and not a.profile_ops and a.time_every == 0
     launch = "eager" if (a.no_graph or not can_graph) else (a.launch or "auto")
     stepper = None
     auto_note = None
@@ -295,6 +299,11 @@ def main():
         ms_graph = probe(lambda i: stepper(losses, batches, i))
         stepper.flush(losses)
         ms_eager = probe(lambda i: train.train_step(losses, model, opt, sched, batches, i, args, defer_d_phase=True))
+        if world > 1:                           # one decision for all ranks: the slowest rank's figures
+            import torch.distributed as dist
+            mm = torch.tensor([ms_graph, ms_eager], dtype=torch.float64, device=dev)
+            dist.all_reduce(mm, op=dist.ReduceOp.MAX)
+            ms_graph, ms_eager = float(mm[0]), float(mm[1])
         from unast_amd.engine import join_streams
         join_streams(); sync()
         auto_note = "auto: graph replay %.2f ms/step vs eager %.2f ms/step in 6 untimed steps each" % (ms_graph, ms_eager)
@@ -433,6 +442,7 @@ def main():
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16x3" if config.NSPLIT == 3 else "bf16", "data": "synthetic",
            "dist_backend": (a.backend if dist_on else None),
+           "gradient_exchange": (None if not dist_on else ("RCCL through the C ABI (unast_comm_*), issued by the stream-replay executor / ddp.py" if native else "torch.distributed all_reduce")),
            "launch_mode": (("hip-graph replay of the captured step (unast_amd.graphed), %d untimed priming calls" % n_prime) if stepper is not None
                            else "eager (one Python launch per kernel)" + ("; gradient buckets all-reduced during the backward (unast_amd.ddp)" if dist_on else ""))
                           + ((" [" + auto_note + "]") if auto_note else ""),

@@ -99,12 +99,15 @@ int unast_colsum_f32(const float* x, int ldx, int rows, int C, float* sum, hipSt
 /* Train-mode BatchNorm1d + activation (1 relu, 2 tanh) + dropout over [rows=B*T, C]: TextPrenet.forward_fcn
  * (src/module.py:223-230) and SpeechPostnet.forward (src/module.py:162-165).  Updates running stats (momentum,
  * unbiased variance) when running_mean != NULL.  ws: 2*C doubles of scratch; have_sums = 1: ws already holds the column
- * sums and sums of squares of x (written by unast_gemm colstats), the statistics pass over x is skipped.
- * bwd: dy_inout is overwritten with d(pre-activation); dgamma/dbeta accumulated (may be NULL). */
+ * sums and sums of squares of x (written by unast_gemm colstats), the statistics pass over x is skipped.  The statistics are
+ * finalized inside the normalising pass itself (no separate launch); num_batches_tracked (may be NULL): the layer's int64 batch
+ * counter, incremented by that same launch (nn.BatchNorm1d's buffer of the same name).
+ * bwd: dy_inout is overwritten with d(pre-activation); dgamma/dbeta accumulated (may be NULL); ws_zeroed = 1: the caller hands
+ * over 2*C doubles that are already zero (no memset launch). */
 int unast_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                  float* running_mean, float* running_var, double* ws, int rows, int C,
                  float eps, float momentum, int act, float drop_p, unsigned int seed, unsigned int stream_id,
-                 int have_sums, hipStream_t stream);
+                 int have_sums, int64_t* num_batches_tracked, hipStream_t stream);
 /* Eval-mode BatchNorm1d + activation (model.eval(): running statistics, no dropout), as evaluate() runs it
  * (src/train.py:484; src/module.py:162-165, 223-230).  mean/rstd: C floats of scratch. */
 int unast_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
@@ -112,7 +115,7 @@ int unast_bn_eval_fwd(const float* x, const float* gamma, const float* beta, con
                       hipStream_t stream);
 int unast_bn_bwd(float* dy_inout, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                  float* dx, float* dgamma, float* dbeta, double* ws, int rows, int C, int act,
-                 float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);
+                 float drop_p, unsigned int seed, unsigned int stream_id, int ws_zeroed, hipStream_t stream);
 
 /* nn.Embedding(padding_idx=0) + emb_dropout + noise_fn (src/module.py:189,226; src/network.py:429-438, 483-487;
  * src/utils.py:40-49).  shift_sos >= 0 builds the decoder input [SOS, ids[:-1]] on the fly. dE is accumulated. */
@@ -306,6 +309,22 @@ int64_t unast_graph_plan_create(void* graph, int nstreams);
 int unast_graph_plan_info(int64_t plan, int* out4);
 int unast_graph_plan_replay(int64_t plan, hipStream_t origin);
 int unast_graph_plan_destroy(int64_t plan);
+/* Gradient exchanges inside a replayed step: nodes captured by unast_allreduce_marker are issued as unast_allreduce on the communicator
+ * given here (allreduces: how many such nodes the plan holds). */
+int unast_graph_plan_allreduces(int64_t plan);
+int unast_graph_plan_set_comm(int64_t plan, int64_t comm);
+
+/* Data-parallel gradient exchange over RCCL / xGMI (csrc/comm.cpp).  New with respect to the reference, which is single-device
+ * (src/utils.py:101-106); the order it has to keep -- generator update before the discriminator phase -- is src/train.py:628-637.
+ * unique_id: 128 bytes made by ONE rank and handed to the others by the launcher (torch.distributed's store, a file, the
+ * environment); init blocks until all `world` ranks have called it.  allreduce: in-place fp32 sum of buf[0, count) over the
+ * ranks, enqueued on `stream`.  marker: what a CAPTURED step records at the place of an all-reduce -- an empty kernel node carrying
+ * (buf, count) that the stream-replay executor turns into unast_allreduce on the node's stream. */
+int unast_comm_unique_id(void* out128);
+int64_t unast_comm_init(const void* unique_id128, int rank, int world);
+int unast_allreduce(int64_t comm, float* buf, int64_t count, hipStream_t stream);
+int unast_allreduce_marker(float* buf, int64_t count, hipStream_t stream);
+int unast_comm_destroy(int64_t comm);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,8 @@ rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
 dist.init_process_group(os.environ.get("TEST_BACKEND", "gloo"), rank=rank, world_size=world)
 dev = torch.device("cuda:0"); train.DEVICE = dev
 torch.cuda.set_device(dev)
-args = make_args(num_layers=1, ae_steps=1, sp_steps=1, d_steps=1, cm_steps=0)
+CM = os.environ.get("TEST_CM", "0") == "1"            # cross-model sub-step LAST (sp_steps = 0): its backward runs an encoder before its modality's decoder
+args = make_args(num_layers=1, ae_steps=1, sp_steps=0 if CM else 1, d_steps=1, cm_steps=1 if CM else 0)
 utils.set_seed(7); utils.set_deterministic(True)
 _, _, model, opt, sched = train.initialize_model(args)
 opt.param_groups[0]["lr"] = 1e-3
@@ -37,13 +38,39 @@ def spy(*a, **k):
     r = _step(*a, **k)
     gnorms.append(opt.grad_norm())            # global norm of the rank-averaged gradients of this phase (one host read; test only)
     return r
-opt.step = spy
-for it in range(2):
-    train.train_step(losses, model, opt, None, dict(unsup=[batch], sup=[batch], disc=[batch]), it, args, defer_d_phase=bool(it))
+if os.environ.get("TEST_GRAPH", "0") != "1":           # (a captured step cannot read a scalar back)
+    opt.step = spy
+GRAPH = os.environ.get("TEST_GRAPH", "0") == "1"      # the captured step replayed by the stream executor, collectives issued from C++
+batches = dict(unsup=[batch], sup=[batch], disc=[batch], cm=[batch])
+if CM:
+    model.speech_m.infer_max_len = model.text_m.infer_max_len = 6
+    so, to = model.speech_m.infer_sequence, model.text_m.infer_sequence
+    model.speech_m.infer_sequence = lambda memory, masks, max_len=6: so(memory, masks, max_len)
+    model.text_m.infer_sequence = lambda memory, masks, max_len=6: to(memory, masks, max_len)
+if GRAPH:
+    from unast_amd.graphed import GraphedTrainStep
+    stepper = GraphedTrainStep(model, opt, None, args)
+    assert stepper.capturable(), "the native communicator should make the distributed step capturable"
+    for it in range(5):
+        stepper(losses, batches, it)
+    stepper.flush(losses)
+    rec = next(iter(stepper.graphs.values()))
+    assert rec.plan and rec.plan_info["allreduces"] >= 5, rec.plan_info
+    print("plan", rec.plan_info)
+else:
+    for it in range(int(os.environ.get("TEST_STEPS", "2"))):
+        train.train_step(losses, model, opt, None, batches, it, args, defer_d_phase=bool(it))
 from unast_amd.engine import join_streams
 join_streams(); torch.cuda.synchronize()
+if os.environ.get("TEST_BACKEND", "gloo") == "nccl" and os.environ.get("UNAST_NATIVE_COMM", "1") != "0":
+    assert ddp._Native.handle and ddp._Native.issued > 0, "the exchange should have gone through unast_allreduce"
 labels = [l[0] for l in ddp._State.log]
-if os.environ.get("UNAST_DDP_OVERLAP", "1") != "0":
+if GRAPH or os.environ.get("TEST_STEPS"):
+    pass
+elif CM and os.environ.get("UNAST_DDP_OVERLAP", "1") != "0":
+    assert sorted(labels[:4]) == ["speech_dec", "speech_enc", "text_dec", "text_enc"], labels
+    assert labels.index("speech_dec") < labels.index("speech_enc") and labels.index("text_dec") < labels.index("text_enc"), labels
+elif os.environ.get("UNAST_DDP_OVERLAP", "1") != "0":
     # per outer step: the four generator buckets in backward order (decoders before encoders), then the D phase's range
     assert len(labels) == 10 and labels[:5] == labels[5:], labels
     assert set(labels[:2]) == {"text_dec", "speech_dec"} and set(labels[2:4]) == {"speech_enc", "text_enc"} and labels[4] == "rest", labels
@@ -54,8 +81,9 @@ if os.environ.get("UNAST_DDP_OVERLAP", "1") != "0":
 else:
     assert labels == ["rest", "rest"] * 2, labels
 a, b = model._store().regions["gen"]
-covered = sorted((l[1], l[2]) for l in ddp._State.log[:4]) if labels[0] != "rest" else [(a, b)]
-assert covered[0][0] == a and covered[-1][1] == b and all(x[1] == y[0] for x, y in zip(covered, covered[1:])), covered
+if not GRAPH and not os.environ.get("TEST_STEPS"):
+    covered = sorted((l[1], l[2]) for l in ddp._State.log[:4]) if labels[0] != "rest" else [(a, b)]
+    assert covered[0][0] == a and covered[-1][1] == b and all(x[1] == y[0] for x, y in zip(covered, covered[1:])), covered
 flat = model._store().flat.detach().cpu()
 if world > 1:
     gathered = [torch.empty_like(flat) for _ in range(world)]
@@ -86,7 +114,7 @@ def _same(a, b):
     """Two runs of the same two outer steps agree: the global norms of the exchanged gradients (a bucket reduced twice, not at
     all, or unscaled would move them by tens of percent) and the losses to accumulation-order noise; the parameters to a few
     Adam steps of that noise (the first updates are +-lr whatever the gradient's size, so near-zero gradients may flip sign)."""
-    assert len(a["gnorms"]) == 4 and len(b["gnorms"]) == 4
+    assert len(a["gnorms"]) == len(b["gnorms"])
     for x, y in zip(a["gnorms"], b["gnorms"]):
         assert abs(x - y) < 2e-4 * abs(y), (a["gnorms"], b["gnorms"])
     for k in a["losses"]:
@@ -114,6 +142,29 @@ def test_single_rank_nccl_executes_the_rccl_path(tmp_path):
     _same(torch.load(str(tmp_path / "nccl") + ".0"), torch.load(str(tmp_path / "ref") + ".0"))
 
 
+def test_two_ranks_cross_model_last_substep_overlap_equals_blocking(tmp_path):
+    """With a cross-model sub-step as the LAST generator sub-step autograd runs the speech encoder's backward before the speech
+    decoder's, and the decoder still adds speech_m.prenet.* gradients into the encoder's bucket: the bucket may only travel after both
+    (ddp._buckets_of).  Overlapped and blocking exchange must give the same gradients."""
+    import torch
+    _run(tmp_path, 2, 29553, TEST_CM="1", TEST_SAVE=str(tmp_path / "ov"))
+    _run(tmp_path, 2, 29555, TEST_CM="1", TEST_SAVE=str(tmp_path / "blk"), UNAST_DDP_OVERLAP="0")
+    _same(torch.load(str(tmp_path / "ov") + ".0"), torch.load(str(tmp_path / "blk") + ".0"))
+
+
+def test_single_rank_nccl_replayed_step_issues_the_collectives_from_cpp(tmp_path):
+    """Under a process group the train step is captured with marker nodes where the gradient buckets are exchanged; the stream-replay
+    executor issues unast_allreduce (RCCL through the C ABI) there.  Five replayed steps equal five eager steps of the torch.distributed path."""
+    import torch
+    _run(tmp_path, 1, 29557, TEST_BACKEND="nccl", UNAST_DDP_FORCE="1", TEST_GRAPH="1", TEST_SAVE=str(tmp_path / "g"))
+    _run(tmp_path, 1, 29559, TEST_BACKEND="nccl", UNAST_DDP_FORCE="1", UNAST_NATIVE_COMM="0", TEST_STEPS="5", TEST_SAVE=str(tmp_path / "e"))
+    a, b = torch.load(str(tmp_path / "g") + ".0"), torch.load(str(tmp_path / "e") + ".0")
+    for k in a["losses"]:
+        assert len(a["losses"][k]) == len(b["losses"][k]) == 5, (k, len(a["losses"][k]), len(b["losses"][k]))
+        for x, y in zip(a["losses"][k], b["losses"][k]):
+            assert abs(x - y) < 2e-3 * max(1.0, abs(y)), (k, a["losses"][k], b["losses"][k])
+
+
 def test_bench_single_rank_torchrun_nccl():
     """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, nccl), with one rank and the forced
     collective path: RCCL initialises, the overlapped exchange runs, one JSON line comes out."""
@@ -125,6 +176,7 @@ def test_bench_single_rank_torchrun_nccl():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["dist_backend"] == "nccl" and d["value"] > 0 and d["losses_finite"]
+    assert "C ABI" in d["gradient_exchange"] and "auto:" in d["launch_mode"], (d["gradient_exchange"], d["launch_mode"])     # (the captured step was a candidate)
 
 
 def test_bench_two_ranks_torchrun_gloo():

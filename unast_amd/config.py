@@ -79,3 +79,8 @@ PANEL_LN = os.environ.get("UNAST_PANEL_LN", "1") != "0"
 # linear1 writes one keep bit per hidden element (relu > 0 and not dropped); linear2's input-gradient GEMM gates with those bits
 # (scalar loads) instead of re-reading the 105 MB hidden activation.
 PANEL_GATE_BITS = os.environ.get("UNAST_PANEL_GATE_BITS", "1") != "0"
+
+# Data-parallel gradient exchange through the C ABI's own RCCL communicator (csrc/comm.cpp: unast_comm_init / unast_allreduce) instead of
+# torch.distributed calls: stream-ordered, one ctypes call per bucket, and -- because the stream-replay executor can issue it from C++ --
+# the captured train step stays usable under a process group.  0 = torch.distributed all_reduce (eager step only).
+NATIVE_COMM = os.environ.get("UNAST_NATIVE_COMM", "1") != "0"

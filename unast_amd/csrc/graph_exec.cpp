@@ -23,7 +23,7 @@
 
 namespace {
 
-enum OpKind { OP_KERNEL = 0, OP_MEMSET = 1, OP_MEMCPY = 2, OP_RECORD = 3, OP_WAIT = 4 };
+enum OpKind { OP_KERNEL = 0, OP_MEMSET = 1, OP_MEMCPY = 2, OP_RECORD = 3, OP_WAIT = 4, OP_ALLREDUCE = 5 };
 
 struct PlanOp {
     int kind;
@@ -32,6 +32,7 @@ struct PlanOp {
     hipKernelNodeParams kp;     // OP_KERNEL
     hipMemsetParams ms;         // OP_MEMSET
     void* cdst; const void* csrc; size_t cbytes; hipMemcpyKind ckind;   // OP_MEMCPY
+    float* rbuf; long long rcount;                                      // OP_ALLREDUCE (a captured unast_allreduce_marker)
 };
 
 struct Plan {
@@ -40,10 +41,14 @@ struct Plan {
     std::vector<hipEvent_t> events;
     hipEvent_t begin = nullptr;
     std::vector<hipEvent_t> ends;
-    int kernels = 0, memsets = 0, memcpys = 0, cross_edges = 0;
+    int kernels = 0, memsets = 0, memcpys = 0, cross_edges = 0, allreduces = 0;
+    int64_t comm = 0;           // RCCL communicator (unast_comm_init) the plan's collectives are issued on
 };
 
 }  // namespace
+
+extern "C" const void* unast_allreduce_marker_func(void);       // comm.cpp
+extern "C" int unast_graph_plan_destroy(int64_t handle);
 
 extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
     hipGraph_t graph = (hipGraph_t)graph_handle;
@@ -98,7 +103,7 @@ extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
         const int v = order[oi];
         pos_in_order[v] = (int)oi;
         hipGraphNodeType type;
-        if (hipGraphNodeGetType(nodes[v], &type) != hipSuccess) { delete plan; unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: hipGraphNodeGetType failed"); return 0; }
+        if (hipGraphNodeGetType(nodes[v], &type) != hipSuccess) { unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: hipGraphNodeGetType failed"); return 0; }
         // stream: continue behind a dependency that is still the tail of its stream (the newest such), else the stream whose branch has
         // ended (its tail has no unplaced successors) or, failing that, the least recently used one
         int s = -1, best = -1;
@@ -134,27 +139,38 @@ extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
         if (type == hipGraphNodeTypeKernel) {
             op.kind = OP_KERNEL;
             if (hipGraphKernelNodeGetParams(nodes[v], &op.kp) != hipSuccess || !op.kp.func || !op.kp.kernelParams) {
-                delete plan; unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: kernel node %d without a kernelParams array", v); return 0;
+                unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: kernel node %d without a kernelParams array", v); return 0;
             }
-            ++plan->kernels;
+            if (op.kp.func == unast_allreduce_marker_func()) {       // a gradient exchange: RCCL is called in its place at replay time
+                op.kind = OP_ALLREDUCE;
+                op.rbuf = *reinterpret_cast<float**>(op.kp.kernelParams[0]);
+                op.rcount = *reinterpret_cast<long long*>(op.kp.kernelParams[1]);
+                if (!op.rbuf || op.rcount <= 0) { unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: bad all-reduce marker (node %d)", v); return 0; }
+                ++plan->allreduces;
+            } else {
+                ++plan->kernels;
+            }
         } else if (type == hipGraphNodeTypeMemset) {
             op.kind = OP_MEMSET;
             if (hipGraphMemsetNodeGetParams(nodes[v], &op.ms) != hipSuccess || op.ms.height > 1 || (op.ms.elementSize != 1 && op.ms.elementSize != 2 && op.ms.elementSize != 4)) {
-                delete plan; unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: unsupported memset node %d", v); return 0;
+                unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: unsupported memset node %d", v); return 0;
             }
             ++plan->memsets;
         } else if (type == hipGraphNodeTypeMemcpy) {
             hipMemcpy3DParms cp;
             if (hipGraphMemcpyNodeGetParams(nodes[v], &cp) != hipSuccess || cp.extent.height > 1 || cp.extent.depth > 1 || cp.srcArray || cp.dstArray ||
                 cp.srcPos.x || cp.srcPos.y || cp.srcPos.z || cp.dstPos.x || cp.dstPos.y || cp.dstPos.z) {
-                delete plan; unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: unsupported memcpy node %d (only 1-D copies)", v); return 0;
+                unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: unsupported memcpy node %d (only 1-D copies)", v); return 0;
             }
             op.kind = OP_MEMCPY; op.cdst = cp.dstPtr.ptr; op.csrc = cp.srcPtr.ptr; op.cbytes = cp.extent.width; op.ckind = cp.kind;
+            if (!op.cdst || !op.csrc || op.cbytes == 0) {            // (a getter that returns zeroed parameters must not become a silent 0-byte copy)
+                unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: memcpy node %d without a pointer / extent", v); return 0;
+            }
             ++plan->memcpys;
         } else if (type == hipGraphNodeTypeEmpty || type == hipGraphNodeTypeEventRecord || type == hipGraphNodeTypeWaitEvent) {
             op.kind = -1;                                            // ordering only: keeps its place on the stream, launches nothing
         } else {
-            delete plan; unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: unsupported node type %d (node %d)", (int)type, v); return 0;
+            unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: unsupported node type %d (node %d)", (int)type, v); return 0;
         }
         ops.push_back(op);
         // the record for cross-stream consumers is emitted right behind the node; whether it is needed is known only later, so every
@@ -171,14 +187,14 @@ extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
     }
     for (auto& op : ops) if (op.kind >= 0) plan->ops.push_back(op);
     // streams, events
-    plan->streams.resize(nstreams);
-    for (int t = 0; t < nstreams; ++t)
-        if (hipStreamCreateWithFlags(&plan->streams[t], hipStreamNonBlocking) != hipSuccess) { unast_set_error(UNAST_ERR_LAUNCH, "unast_graph_plan_create: hipStreamCreate failed"); return 0; }
-    for (auto& e : plan->events)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { unast_set_error(UNAST_ERR_LAUNCH, "unast_graph_plan_create: hipEventCreate failed"); return 0; }
-    hipEventCreateWithFlags(&plan->begin, hipEventDisableTiming);
-    plan->ends.resize(nstreams);
-    for (auto& e : plan->ends) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    plan->streams.assign(nstreams, nullptr);
+    plan->ends.assign(nstreams, nullptr);
+    bool ok = true;
+    for (int t = 0; t < nstreams && ok; ++t) ok = hipStreamCreateWithFlags(&plan->streams[t], hipStreamNonBlocking) == hipSuccess;
+    for (size_t i = 0; i < plan->events.size() && ok; ++i) ok = hipEventCreateWithFlags(&plan->events[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&plan->begin, hipEventDisableTiming) == hipSuccess;
+    for (int t = 0; t < nstreams && ok; ++t) ok = hipEventCreateWithFlags(&plan->ends[t], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_LAUNCH, "unast_graph_plan_create: stream / event creation failed"); return 0; }
     return (int64_t)(intptr_t)plan;
 }
 
@@ -189,9 +205,22 @@ extern "C" int unast_graph_plan_info(int64_t handle, int* out4) {
     return UNAST_OK;
 }
 
+extern "C" int unast_graph_plan_allreduces(int64_t handle) {
+    Plan* plan = (Plan*)(intptr_t)handle;
+    return plan ? plan->allreduces : -1;
+}
+
+extern "C" int unast_graph_plan_set_comm(int64_t handle, int64_t comm) {
+    Plan* plan = (Plan*)(intptr_t)handle;
+    UNAST_REQUIRE(plan, "unast_graph_plan_set_comm: null plan");
+    plan->comm = comm;
+    return UNAST_OK;
+}
+
 extern "C" int unast_graph_plan_replay(int64_t handle, hipStream_t origin) {
     Plan* plan = (Plan*)(intptr_t)handle;
     UNAST_REQUIRE(plan, "unast_graph_plan_replay: null plan");
+    UNAST_REQUIRE(plan->allreduces == 0 || plan->comm, "unast_graph_plan_replay: the plan holds %d gradient exchanges but no communicator (unast_graph_plan_set_comm)", plan->allreduces);
     // everything enqueued on the caller's stream so far happens before the plan; the caller's stream waits for all of it at the end
     if (hipEventRecord(plan->begin, origin) != hipSuccess) return unast_set_error(UNAST_ERR_LAUNCH, "unast_graph_plan_replay: hipEventRecord failed");
     for (auto s : plan->streams) hipStreamWaitEvent(s, plan->begin, 0);
@@ -208,6 +237,7 @@ extern "C" int unast_graph_plan_replay(int64_t handle, hipStream_t origin) {
             case OP_MEMCPY: e = hipMemcpyAsync(op.cdst, op.csrc, op.cbytes, op.ckind, s); break;
             case OP_RECORD: e = hipEventRecord(plan->events[op.event], s); break;
             case OP_WAIT: e = hipStreamWaitEvent(s, plan->events[op.event], 0); break;
+            case OP_ALLREDUCE: { const int rc = unast_allreduce(plan->comm, op.rbuf, op.rcount, s); if (rc) return rc; break; }
             default: break;
         }
         if (e != hipSuccess) return unast_set_error(UNAST_ERR_LAUNCH, "unast_graph_plan_replay: op kind %d failed: %s", op.kind, hipGetErrorString(e));

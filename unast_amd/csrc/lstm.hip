@@ -17,8 +17,10 @@ __device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn
 #define FCH 16            // forward: timesteps of input projections held in registers per chunk
 #define BCH 8             // backward: timesteps of saved state held in registers per chunk
 
-// xproj [Bd,T,ndir*LG] (no bias), y [Bd,T,ndir*LH] (pre-zeroed), gates [Bd,T,ndir,LG], cs [Bd,T,ndir,LH],
-// hprev [Bd,T,ndir,LH] (pre-zeroed), hfinal [Bd, ndir*LH]
+// xproj [Bd,T,ndir*LG] (no bias), y [Bd,T,ndir*LH], gates [Bd,T,ndir,LG], cs [Bd,T,ndir,LH], hprev [Bd,T,ndir,LH], hfinal [Bd, ndir*LH].
+// y and hprev of the padded steps t >= len are written as zeros here (they are GEMM operands of the next layer / of the weight
+// gradients over all Bd*T rows): the caller allocates them uninitialised -- pre-zeroing them with a fill launch each was 26 MB of
+// memset per tensor and call at config 3.
 //
 // One barrier per timestep: thread j (wave w = j>>6 owns gate type i/f/g/o) computes its gate pre-activation from the
 // wave-private copy of h, publishes the activated gate in a double-buffered LDS array, and after the barrier EVERY wave
@@ -43,6 +45,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
     }
     const float bias = b_ih[dir * bias_dir_stride + j] + b_hh[dir * bias_dir_stride + j];
     h_lds[wave][u] = 0.f;
+    for (int t = max(len, 0) + wave; t < T; t += 4) {                // padded steps: wave w clears every 4th one
+        y[((size_t)b * T + t) * ((size_t)ndir * LH) + dir * LH + u] = 0.f;
+        hprev[(((size_t)b * T + t) * ndir + dir) * LH + u] = 0.f;
+    }
     if (len <= 0) {                                                  // (uniform) empty sequence: final state = initial state
         if (wave == 0) hfinal[(size_t)b * (ndir * LH) + dir * LH + u] = 0.f;
         return;
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
 }
 
 // Backward through time.  dy [Bd,T,ndir*LH] (may be null), dhfinal [Bd,ndir*LH] (may be null),
-// dgates [Bd,T,ndir,LG] (pre-zeroed; receives d(pre-activation gates) for valid steps).
+// dgates [Bd,T,ndir,LG]: receives d(pre-activation gates) for the valid steps and zeros for the padded ones (t >= len).
 // One barrier per step: every wave redundantly forms the four gate gradients of unit k = lane (from the shared dh),
 // keeps them in a wave-private LDS copy, computes its quarter (gate rows 64*wave..) of dh_prev = dg . W_hh, and after
 // the barrier every wave sums the four partials.  Saved gates / cell states / dy of BCH steps are register-resident
@@ -144,6 +150,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
             v[i][6] = dy ? dy[((size_t)b * T + t) * (ndir * LH) + dir * LH + k] : 0.f;
         }
     };
+    for (int t = max(len, 0); t < T; ++t) dgates[(((size_t)b * T + t) * ndir + dir) * LG + j] = 0.f;       // padded steps: 1 KB per step
     if (len <= 0) return;                                   // (uniform)
     float* dgr = dgates + (((size_t)b * T + t0) * ndir + dir) * LG + k;        // advanced by one time step per iteration
     const ptrdiff_t dg_inc = (ptrdiff_t)tstep * ndir * LG;

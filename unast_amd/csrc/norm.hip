@@ -248,40 +248,63 @@ __global__ __launch_bounds__(256) void colsum_scalar_kernel(const float* __restr
     }
 }
 
-// BatchNorm statistics finalize: mean/rstd (biased variance) + running-stat update (momentum, unbiased variance).
-__global__ void bn_finalize_kernel(const double* __restrict__ s1, const double* __restrict__ s2, int C, double n, float eps,
-                                   float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mu = s1[c] / n;
-    double var = s2[c] / n - mu * mu;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)mu;
-    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-        const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-    }
-}
-
 __device__ __forceinline__ float act_fwd(float x, int act) { return act == 1 ? fmaxf(x, 0.f) : (act == 2 ? tanhf(x) : x); }
 
-// y = dropout(act((x-mean)*rstd*gamma + beta));  act: 0 none, 1 relu, 2 tanh.  rows x C, float4 per thread.
-__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ y, int rows, int C,
+// Train-mode BatchNorm forward in ONE pass over x: y = dropout(act((x-mean)*rstd*gamma + beta)); act: 0 none, 1 relu, 2 tanh.
+// The batch statistics are finalized HERE from the fp64 column sums s1 = sum x, s2 = sum x^2 (the conv GEMM's epilogue or colsum_kernel
+// produced them): every thread turns the sums of its 4 channels into mean / rstd (biased variance) before its first row -- its channel
+// quad never changes when the grid's thread count is a multiple of C/4 -- so the former bn_finalize launch is gone; workgroup 0 also
+// stores mean / rstd for the backward, updates the running statistics (momentum, unbiased variance) and counts the batch
+// (num_batches_tracked += 1, formerly a torch add per layer and step).  stats_given: mean / rstd are read (eval mode) instead.
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const double* __restrict__ s1, const double* __restrict__ s2,
+                                                           double n, float eps, float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           long long* __restrict__ num_batches_tracked, int stats_given,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, int rows, int C,
                                                            int act, uint32_t drop_thresh, float drop_scale, uint32_t seed, uint32_t stream) {
     const int cq = C >> 2;
     const size_t total = (size_t)rows * cq;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const bool fixed = ((size_t)gridDim.x * 256) % (size_t)cq == 0;           // this thread's channel quad is the same in every iteration
+    float m[4], rs[4];
+    auto stats = [&](int c) {
+        if (stats_given) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { m[e] = mean[c + e]; rs[e] = rstd[c + e]; }
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double mu = s1[c + e] / n;
+            double var = s2[c + e] / n - mu * mu;
+            if (var < 0.0) var = 0.0;
+            m[e] = (float)mu;
+            rs[e] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    };
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (fixed) stats((int)(i0 % cq) * 4);
+    if (!stats_given && blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const double mu = s1[c] / n;
+            double var = s2[c] / n - mu * mu;
+            if (var < 0.0) var = 0.0;
+            mean[c] = (float)mu;
+            rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean) {
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+                const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
+        }
+        if (num_batches_tracked && threadIdx.x == 0) *num_batches_tracked += 1;
+    }
+    for (size_t i = i0; i < total; i += (size_t)gridDim.x * 256) {
         const int r = (int)(i / cq), c = (int)(i - (size_t)r * cq) * 4;
+        if (!fixed) stats(c);
         float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + c);
-        float4 m = *reinterpret_cast<const float4*>(mean + c), s = *reinterpret_cast<const float4*>(rstd + c);
         float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
-        float o[4] = {(v.x - m.x) * s.x * g.x + b.x, (v.y - m.y) * s.y * g.y + b.y, (v.z - m.z) * s.z * g.z + b.z,
-                      (v.w - m.w) * s.w * g.w + b.w};
+        float o[4] = {(v.x - m[0]) * rs[0] * g.x + b.x, (v.y - m[1]) * rs[1] * g.y + b.y, (v.z - m[2]) * rs[2] * g.z + b.z,
+                      (v.w - m[3]) * rs[3] * g.w + b.w};
         uint32_t rkey = drop_thresh ? rng_row_key(seed, stream, (uint32_t)r) : 0u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -459,7 +482,7 @@ extern "C" int unast_colsum_f32(const float* x, int ldx, int rows, int C, float*
 extern "C" int unast_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                             float* running_mean, float* running_var, double* ws /* 2*C doubles */, int rows, int C,
                             float eps, float momentum, int act, float drop_p, unsigned int seed, unsigned int stream_id,
-                            int have_sums, hipStream_t stream) {
+                            int have_sums, int64_t* num_batches_tracked, hipStream_t stream) {
     UNAST_REQUIRE(x && gamma && beta && y && mean && rstd && ws, "unast_bn_fwd: null pointer");
     int blocks, rpb;
     UNAST_REQUIRE(colsum_geometry(rows, C, &blocks, &rpb) == 0, "unast_bn_fwd: need C%%4==0, C<=1024 (C=%d)", C);
@@ -467,9 +490,8 @@ extern "C" int unast_bn_fwd(const float* x, const float* gamma, const float* bet
         hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream);
         hipLaunchKernelGGL((colsum_kernel<double>), dim3(blocks), dim3(256), 0, stream, x, C, rows, C, rpb, ws, ws + C);
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, ws + C, C, (double)rows, eps, momentum,
-                       mean, rstd, running_mean, running_var);
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for((size_t)rows * (C / 4), 256)), dim3(256), 0, stream, x, mean, rstd, gamma, beta, y,
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for((size_t)rows * (C / 4), 256)), dim3(256), 0, stream, x, ws, ws + C, (double)rows, eps, momentum,
+                       mean, rstd, running_mean, running_var, (long long*)num_batches_tracked, 0, gamma, beta, y,
                        rows, C, act, drop_threshold(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, stream_id);
     return unast_check_launch("unast_bn_fwd");
 }
@@ -489,19 +511,19 @@ extern "C" int unast_bn_eval_fwd(const float* x, const float* gamma, const float
     UNAST_REQUIRE(x && gamma && beta && running_mean && running_var && y && mean && rstd, "unast_bn_eval_fwd: null pointer");
     UNAST_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "unast_bn_eval_fwd: need rows>0, C%%4==0 (rows=%d C=%d)", rows, C);
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, running_mean, running_var, C, eps, mean, rstd);
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for((size_t)rows * (C / 4), 256)), dim3(256), 0, stream, x, mean, rstd, gamma, beta, y,
-                       rows, C, act, 0u, 1.f, 0u, 0u);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for((size_t)rows * (C / 4), 256)), dim3(256), 0, stream, x, (const double*)nullptr, (const double*)nullptr, 1.0, eps,
+                       0.f, mean, rstd, (float*)nullptr, (float*)nullptr, (long long*)nullptr, 1, gamma, beta, y, rows, C, act, 0u, 1.f, 0u, 0u);
     return unast_check_launch("unast_bn_eval_fwd");
 }
 
 extern "C" int unast_bn_bwd(float* dy_inout, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                             float* dx, float* dgamma, float* dbeta, double* ws /* 2*C doubles */, int rows, int C, int act,
-                            float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream) {
+                            float drop_p, unsigned int seed, unsigned int stream_id, int ws_zeroed, hipStream_t stream) {
     UNAST_REQUIRE(dy_inout && x && mean && rstd && gamma && beta && dx && ws, "unast_bn_bwd: null pointer");
     UNAST_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "unast_bn_bwd: dgamma/dbeta must both be given or both null");
     int blocks, rpb;
     UNAST_REQUIRE(colsum_geometry(rows, C, &blocks, &rpb) == 0, "unast_bn_bwd: need C%%4==0, C<=1024 (C=%d)", C);
-    hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream);
+    if (!ws_zeroed) hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, stream);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, stream, dy_inout, x, mean, rstd, gamma, beta, rows, C, rpb, act,
                        drop_threshold(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, stream_id, ws, ws + C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)rows * (C / 4), 256)), dim3(256), 0, stream, dy_inout, x, mean, rstd, gamma,

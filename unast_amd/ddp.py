@@ -48,6 +48,56 @@ class _State:
     scale_fn = None         # test hook: CPU tensors have no HIP scale kernel
 
 
+class _Native:
+    handle = 0              # unast_comm_init communicator of this process (0: none)
+    tried = False
+    issued = 0              # collectives issued through it (tests)
+
+
+def native_comm():
+    """The RCCL communicator behind the C ABI for the current process group (nccl backend, CUDA tensors), created on first use: rank 0
+    draws the unique id (unast_comm_unique_id), the launcher's process group broadcasts it, every rank calls unast_comm_init, and one
+    small all-reduce checks the result against the group's size.  0 when disabled (config.NATIVE_COMM), not distributed, another
+    backend, or when the check fails -- the exchange then stays on torch.distributed."""
+    if _Native.tried:
+        return _Native.handle
+    dist = _dist()
+    if dist is None:
+        return 0
+    _Native.tried = True
+    from . import config
+    if not config.NATIVE_COMM or dist.get_backend() != "nccl" or not torch.cuda.is_available():
+        return 0
+    import ctypes
+    from ._lib import lib
+    L = lib()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ids = [None]
+    if rank == 0:
+        buf = (ctypes.c_char * 128)()
+        if L.unast_comm_unique_id(ctypes.addressof(buf)) != 0:
+            buf = None
+        ids[0] = bytes(buf) if buf is not None else b""
+    dist.broadcast_object_list(ids, src=0)
+    if len(ids[0]) != 128:
+        return 0
+    b = ctypes.create_string_buffer(ids[0], 128)
+    h = L.unast_comm_init(ctypes.addressof(b), rank, world)
+    if not h:
+        return 0
+    probe = torch.ones(256, dtype=torch.float32, device="cuda")
+    ok = L.unast_allreduce(h, probe.data_ptr(), probe.numel(), ops._stream()) == 0
+    torch.cuda.synchronize()
+    ok = ok and bool((probe == float(world)).all())
+    flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # every rank takes the same decision
+    if float(flag) < 1.0:
+        L.unast_comm_destroy(h)
+        return 0
+    _Native.handle = h
+    return h
+
+
 def _dist():
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
@@ -152,6 +202,30 @@ def _issue(store, label, rng, overlap):
     dist = _dist()
     a, b = rng
     buf = store.grad[a:b]
+    h = native_comm() if buf.is_cuda else 0
+    if h:
+        # RCCL through the C ABI: stream-ordered behind `s`; while a HIP graph is being captured a marker node stands in for the call and
+        # the stream-replay executor issues the collective there (csrc/graph_exec.cpp)
+        from ._lib import lib, check
+        from . import engine
+        cur = torch.cuda.current_stream()
+        s = _issue_stream() if overlap else cur
+        for name in list(engine._Streams.used):          # weight / LayerNorm-parameter gradients live on the companion streams
+            if name.endswith("_w"):
+                c = engine._side(name)
+                if c != s:
+                    s.wait_stream(c)
+        with torch.cuda.stream(s):
+            if torch.cuda.is_current_stream_capturing():
+                check(lib().unast_allreduce_marker(buf.data_ptr(), buf.numel(), ops._stream()), "unast_allreduce_marker")
+            else:
+                check(lib().unast_allreduce(h, buf.data_ptr(), buf.numel(), ops._stream()), "unast_allreduce")
+            if s != cur:
+                _State.pending.append(s.record_event())
+        _Native.issued += 1
+        _State.issued.append(rng)
+        _State.log.append((label, a, b))
+        return
     if buf.is_cuda and overlap:
         from . import engine
         s = _issue_stream()
@@ -200,7 +274,10 @@ def finish(store, ranges):
             _issue(store, "rest", part, overlap=False)
             n += 1
     for work in _State.pending:
-        work.wait()                                        # the current stream waits for that collective (no host block with RCCL)
+        if isinstance(work, torch.cuda.Event):
+            torch.cuda.current_stream().wait_event(work)   # native path: the collective is stream-ordered before this event
+        else:
+            work.wait()                                    # the current stream waits for that collective (no host block with RCCL)
     scale = _State.scale_fn or ops.scale_inplace
     ws = dist.get_world_size()
     for a, b in ranges:

@@ -238,7 +238,23 @@ def posenc(cx, tape, x, pe, T, gate=None):
 # ---------------------------------------------------------------------------------------------------------------
 # Text side
 # ---------------------------------------------------------------------------------------------------------------
-def conv_bn_act(cx, tape, x, B, T, conv_pre, bn_pre, pad_left, act, drop, bn_buffers, residual=None, x_ld_view=None):
+class ZeroPool:
+    """fp64 scratch of a whole conv + BatchNorm stack, zeroed by ONE fill launch: per stage 2C doubles for the conv GEMM's column
+    sums (forward) and 2C for the backward's reduction -- instead of a fill per stage and pass (17 + 14 launches per step)."""
+
+    def __init__(self, stages, C, device):
+        self.buf = torch.zeros(stages * 4 * C, dtype=torch.float64, device=device)
+        self.C, self.i = C, 0
+
+    def take(self, Cout):
+        if Cout != self.C or (self.i + 1) * 4 * self.C > self.buf.numel():
+            return torch.zeros(4 * Cout, dtype=torch.float64, device=self.buf.device)
+        w = self.buf[self.i * 4 * self.C:(self.i + 1) * 4 * self.C]
+        self.i += 1
+        return w
+
+
+def conv_bn_act(cx, tape, x, B, T, conv_pre, bn_pre, pad_left, act, drop, bn_buffers, residual=None, x_ld_view=None, pool=None):
     """dropout(act(BN_train(conv1d_k5(x)))) — one stage of TextPrenet.forward_fcn / SpeechPostnet.forward
     (src/module.py:162-165, 223-230).  x: Var [B*T, Cin]."""
     Wp, b = cx.P[conv_pre + "conv.weight"], cx.P[conv_pre + "conv.bias"]
@@ -246,10 +262,9 @@ def conv_bn_act(cx, tape, x, B, T, conv_pre, bn_pre, pad_left, act, drop, bn_buf
     x3 = x.v.view(B, T, -1)[..., :Cin] if x.v.shape[1] != Cin else x.v.view(B, T, Cin)
     c = _empty(B, T, Cout, like=x.v)
     fused_stats = cx.training and config.CONV_BN_STATS
-    if fused_stats:          # sum / sum of squares per channel come out of the conv GEMM's epilogue
-        ws = torch.zeros(2 * Cout, dtype=torch.float64, device=x.v.device)
-    else:
-        ws = torch.empty(2 * Cout, dtype=torch.float64, device=x.v.device)
+    # [0, 2C): sum / sum of squares per channel out of the conv GEMM's epilogue; [2C, 4C): the backward's column sums (both pre-zeroed)
+    ws4 = pool.take(Cout) if (pool is not None and cx.training) else torch.zeros(4 * Cout, dtype=torch.float64, device=x.v.device)
+    ws, ws_b = ws4[:2 * Cout], ws4[2 * Cout:]
     ops.conv_fwd(x3, Wp, b, c, pad_left, colstats=ws if fused_stats else None)
     p = cx.p(drop)
     s = cx.stream()
@@ -259,8 +274,8 @@ def conv_bn_act(cx, tape, x, B, T, conv_pre, bn_pre, pad_left, act, drop, bn_buf
     rm, rv = bn_buffers[bn_pre + "running_mean"], bn_buffers[bn_pre + "running_var"]
     gamma, beta = cx.P[bn_pre + "weight"], cx.P[bn_pre + "bias"]
     if cx.training:
-        ops.bn_fwd(c.view(N, Cout), gamma, beta, y, mean, rstd, rm, rv, ws, act, drop_p=p, seed=cx.seed, stream_id=s, have_sums=fused_stats)
-        bn_buffers[bn_pre + "num_batches_tracked"] += 1
+        ops.bn_fwd(c.view(N, Cout), gamma, beta, y, mean, rstd, rm, rv, ws, act, drop_p=p, seed=cx.seed, stream_id=s, have_sums=fused_stats,
+                   num_batches_tracked=bn_buffers[bn_pre + "num_batches_tracked"])
     else:
         if tape is not None:
             raise NotImplementedError("eval-mode BatchNorm has no backward on this path; evaluate() runs under torch.no_grad()")
@@ -275,8 +290,8 @@ def conv_bn_act(cx, tape, x, B, T, conv_pre, bn_pre, pad_left, act, drop, bn_buf
             st = cx.st
             dy = out.g if out.g.is_contiguous() else out.g.contiguous()
             dc = _empty(N, Cout, like=y)
-            ops.bn_bwd(dy, c.view(N, Cout), mean, rstd, gamma, beta, dc, st.g(bn_pre + "weight"), st.g(bn_pre + "bias"), ws, act,
-                       drop_p=p, seed=seed, stream_id=s)
+            ops.bn_bwd(dy, c.view(N, Cout), mean, rstd, gamma, beta, dc, st.g(bn_pre + "weight"), st.g(bn_pre + "bias"), ws_b, act,
+                       drop_p=p, seed=seed, stream_id=s, ws_zeroed=True)
             gW = st.g(conv_pre + "conv.weight")
             dc3 = dc.view(B, T, Cout)
             if gW is not None:
@@ -315,8 +330,9 @@ def text_encode(cx, tape, m, ids, lens, noise):
     B, T = ids.shape
     a = m.args
     x = text_embed(cx, tape, ids, T, a.t_pre_drop, noise, -1)
+    pool = ZeroPool(3, cx.P["text_m.prenet.conv1.conv.weight"].shape[0], ids.device) if cx.training else None
     for i in (1, 2, 3):
-        x = conv_bn_act(cx, tape, x, B, T, "text_m.prenet.conv%d." % i, "text_m.prenet.batch_norm%d." % i, 2, 1, a.t_pre_drop, m.buffers_dict)
+        x = conv_bn_act(cx, tape, x, B, T, "text_m.prenet.conv%d." % i, "text_m.prenet.batch_norm%d." % i, 2, 1, a.t_pre_drop, m.buffers_dict, pool=pool)
     x = posenc(cx, tape, x, m.pe, T)
     return encoder_stack(cx, tape, x, lens, "text_m.encoder.transformer_encoder.layers.", a.num_layers, B, T, a.nhead, a.e_drop)
 
@@ -448,10 +464,11 @@ def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk):
             ops.linear_dgrad(dh[:, :M + 1], Wh, dx)
             acc(x, dx)
         tape.record(bwd_head)                                       # runs after every postnet closure
-    y = conv_bn_act(cx, tape, pre, B, T, "speech_m.postnet.conv1.", "speech_m.postnet.pre_batchnorm.", 4, 2, a.s_post_drop, m.buffers_dict)
+    pool = ZeroPool(4, cx.P["speech_m.postnet.conv1.conv.weight"].shape[0], mel.device) if cx.training else None
+    y = conv_bn_act(cx, tape, pre, B, T, "speech_m.postnet.conv1.", "speech_m.postnet.pre_batchnorm.", 4, 2, a.s_post_drop, m.buffers_dict, pool=pool)
     for i in range(3):
         y = conv_bn_act(cx, tape, y, B, T, "speech_m.postnet.conv_list.%d." % i, "speech_m.postnet.batch_norm_list.%d." % i, 4, 2,
-                        a.s_post_drop, m.buffers_dict)
+                        a.s_post_drop, m.buffers_dict, pool=pool)
     Wp2, b2 = cx.P["speech_m.postnet.conv2.conv.weight"], cx.P["speech_m.postnet.conv2.conv.bias"]
     post = _empty(B, T, M, like=mel)
     C = y.v.shape[1]
@@ -497,10 +514,10 @@ def lstm_discriminator(cx, tape, m, x, lens, Bd, T, need_input_grad=True):
         bhh = st.span(names[3], last[3], (ndir * G4,))
         xproj = _empty(Bd * T, ndir * G4, device=dev)
         ops.linear_fwd(inp.v, Wih, None, xproj)
-        y = torch.zeros(Bd, T, ndir * Hh, dtype=torch.float32, device=dev)
+        y = _empty(Bd, T, ndir * Hh, device=dev)                          # (the recurrence kernels write zeros at the padded steps themselves)
         gates = _empty(Bd, T, ndir, G4, device=dev)
         cs = _empty(Bd, T, ndir, Hh, device=dev)
-        hprev = torch.zeros(Bd, T, ndir, Hh, dtype=torch.float32, device=dev)
+        hprev = _empty(Bd, T, ndir, Hh, device=dev)
         hfin = _empty(Bd, ndir * Hh, device=dev)
         ops.lstm_fwd(xproj.view(Bd, T, ndir * G4), Whh, bih, bhh, lens, y, gates, cs, hprev, hfin, ndir, G4 * Hh, G4)
         yv = Var(y.view(Bd * T, ndir * Hh))
@@ -560,7 +577,7 @@ def lstm_discriminator(cx, tape, m, x, lens, Bd, T, need_input_grad=True):
                 dhf = dr
             dy = None
             for rec in reversed(saved):
-                dg = torch.zeros(Bd, T, ndir, G4, dtype=torch.float32, device=dev)
+                dg = _empty(Bd, T, ndir, G4, device=dev)
                 ops.lstm_bwd(dy, dhf, rec["Whh"], rec["gates"], rec["cs"], lens, dg, ndir, G4 * Hh)
                 dhf = None                                          # only the top layer's final state feeds the head
                 dg2 = dg.view(Bd * T, ndir * G4)

@@ -66,7 +66,9 @@ class GraphedTrainStep:
 
     # ---- plumbing ------------------------------------------------------------------------------------------------
     def capturable(self):
-        return getattr(self.args, "cm_steps", 0) == 0 and not ddp.active()
+        # under a process group the step is capturable when the gradient exchange runs through the C ABI's own RCCL communicator: the
+        # capture then holds marker nodes and the stream-replay executor issues the collectives (ddp.native_comm, csrc/comm.cpp)
+        return getattr(self.args, "cm_steps", 0) == 0 and (not ddp.active() or bool(ddp.native_comm()))
 
     def _signature(self, batches):
         a = self.args
@@ -99,7 +101,9 @@ class GraphedTrainStep:
             T.freeze_model_parameters(model.discriminator)
         accum = a.ae_steps + a.sp_steps
         subs = [(T.train_ae_step, b) for b in self.static["unsup"]] + [(T.train_sp_step, b) for b in self.static["sup"]]
-        for fn, b in subs:
+        for i, (fn, b) in enumerate(subs):
+            if i == len(subs) - 1:
+                ddp.arm()                      # last generator sub-step: gradient buckets travel during its backward (no-op when not distributed)
             fn(losses, model, b, 0, accum, a)
         T.optimizer_step(model, self.opt, a)
 
@@ -199,7 +203,8 @@ class GraphedTrainStep:
         finally:
             T.SYNC_LOSSES = sync_flag
         rec.plan, rec.plan_info = 0, None
-        if REPLAY in ("streams", "auto"):
+        distributed = ddp.active()
+        if REPLAY in ("streams", "auto") or distributed:
             from ._lib import lib
             import ctypes
             rec.plan = lib().unast_graph_plan_create(rec.graph.raw_cuda_graph(), REPLAY_STREAMS)
@@ -207,13 +212,20 @@ class GraphedTrainStep:
                 info = (ctypes.c_int * 4)()
                 lib().unast_graph_plan_info(rec.plan, ctypes.addressof(info))
                 rec.plan_info = dict(mode="streams", kernels=info[0], memsets=info[1], memcpys=info[2], cross_stream_edges=info[3], streams=REPLAY_STREAMS)
-                if REPLAY == "auto" and info[3] < AUTO_MIN_CROSS_EDGES:
+                nar = lib().unast_graph_plan_allreduces(rec.plan)
+                rec.plan_info["allreduces"] = nar
+                if nar > 0:
+                    lib().unast_graph_plan_set_comm(rec.plan, ddp.native_comm())
+                if REPLAY == "auto" and info[3] < AUTO_MIN_CROSS_EDGES and nar == 0 and not distributed:
                     lib().unast_graph_plan_destroy(rec.plan)
                     rec.plan = 0
                     rec.plan_info["mode"] = "hipGraphLaunch (nearly linear graph)"
             else:
                 rec.plan_info = dict(mode="hipGraphLaunch (fallback: %s)" % lib().unast_last_error().decode())
         if not rec.plan:
+            if distributed:
+                raise RuntimeError("GraphedTrainStep: a distributed step needs the stream-replay executor (its gradient exchanges are marker "
+                                   "nodes); plan creation failed: %s" % rec.plan_info)
             rec.graph.instantiate()
         rec.ranges = list(self.opt.captured_ranges)
         self.graphs[sig] = rec

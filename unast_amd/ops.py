@@ -443,10 +443,11 @@ def colsum(x2d, out):
     check(lib().unast_colsum_f32(_p(x2d), x2d.stride(0), rows, C, _p(out), _stream()), "unast_colsum_f32")
 
 
-def bn_fwd(x2d, gamma, beta, y, mean, rstd, running_mean, running_var, ws, act, drop_p=0.0, seed=0, stream_id=0, eps=1e-5, momentum=0.1, have_sums=False):
+def bn_fwd(x2d, gamma, beta, y, mean, rstd, running_mean, running_var, ws, act, drop_p=0.0, seed=0, stream_id=0, eps=1e-5, momentum=0.1, have_sums=False,
+           num_batches_tracked=None):
     rows, C = x2d.shape
     check(lib().unast_bn_fwd(_p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(running_mean), _p(running_var), _p(ws), rows, C,
-                             eps, momentum, act, drop_p, seed & 0xFFFFFFFF, stream_id, int(have_sums), _stream()), "unast_bn_fwd")
+                             eps, momentum, act, drop_p, seed & 0xFFFFFFFF, stream_id, int(have_sums), _p(num_batches_tracked), _stream()), "unast_bn_fwd")
 
 
 def bn_eval_fwd(x2d, gamma, beta, running_mean, running_var, y, mean, rstd, act, eps=1e-5):
@@ -455,10 +456,10 @@ def bn_eval_fwd(x2d, gamma, beta, running_mean, running_var, y, mean, rstd, act,
                                   eps, act, _stream()), "unast_bn_eval_fwd")
 
 
-def bn_bwd(dy_inout, x2d, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, act, drop_p=0.0, seed=0, stream_id=0):
+def bn_bwd(dy_inout, x2d, mean, rstd, gamma, beta, dx, dgamma, dbeta, ws, act, drop_p=0.0, seed=0, stream_id=0, ws_zeroed=False):
     rows, C = x2d.shape
     check(lib().unast_bn_bwd(_p(dy_inout), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta), _p(ws), rows, C,
-                             act, drop_p, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_bn_bwd")
+                             act, drop_p, seed & 0xFFFFFFFF, stream_id, int(ws_zeroed), _stream()), "unast_bn_bwd")
 
 
 # ---- embedding / positional encoding / masks ---------------------------------------------------------------
