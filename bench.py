@@ -86,6 +86,11 @@ class OpTimer:
             return tuple(int(x) for x in a[idx:idx + 5])          # B, H, Tq, Tk, causal
         if n == "wgrad_group":
             return a[0]                                           # ((out, in, tokens, has_bias), ...)
+        if n == "panel_gemm":
+            # (M, N, K, extra [M,N] operands the epilogue reads or writes beyond C: residual, gate, the LayerNorm output)
+            A, N = a[0], a[3]
+            extra = int(k.get("R") is not None) + int(k.get("G") is not None) + int(k.get("ln") is not None)
+            return (int(A.shape[0]), int(N), int(k.get("K") or A.shape[1]), extra)
         return ()
 
     def __exit__(self, *exc):
@@ -118,6 +123,18 @@ def gemm_bytes(key):
     return 4.0 * (a_el + b_el + M * N * (1 + extra))
 
 
+def panel_flops(key):
+    M, N, K, _ = key
+    return 2.0 * M * N * K
+
+
+def panel_bytes(key):
+    """Row-panel GEMM: A once, the weight planes once (2 x 2 bytes per element), C once, plus the extra [M,N] operands (residual read, LayerNorm
+    output written)."""
+    M, N, K, extra = key
+    return 4.0 * (M * K + N * K + M * N * (1 + extra))
+
+
 def group_flops(key):
     return sum(2.0 * M * N * K for (M, N, K, _) in key)
 
@@ -132,6 +149,32 @@ def attn_flops(name, key):
     pairs = Tq * (Tq + 1) / 2 if causal else Tq * Tk
     per = 4.0 * B * H * pairs * 64               # QK^T + PV
     return per if name == "attn_fwd" else per * 2.5      # backward: 5 products (S, dP, dV, dK, dQ)
+
+
+def csrc_digest():
+    """sha256 over the kernel sources: what tools/profile_manifest.py records next to the rocprofv3 summaries it files under profiles/."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "unast_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "unast_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(ROOT, "unast_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiles_fresh():
+    """True when the committed profile summaries this line quotes were taken from the present kernel sources (profiles/manifest.json), False
+    when csrc/ has changed since (the quoted rocprof / PMC figures are then history, not this build), None without a manifest."""
+    mp = os.path.join(ROOT, "profiles", "manifest.json")
+    if not os.path.exists(mp):
+        return None
+    try:
+        ok = json.load(open(mp)).get("csrc_sha16") == csrc_digest()
+    except Exception:
+        return None
+    if not ok:
+        print("bench.py: profiles/manifest.json was written for other kernel sources: roofline.traffic / rocprof_avg_launch_us quote an older build", file=sys.stderr)
+    return ok
 
 
 def make_batch(B, Tt, Tm, seed):
@@ -315,7 +358,7 @@ def main():
     # In-region HIP-event pairs exist only in the eager form (a replayed graph has no per-kernel host hooks) and only with --time-every:
     # they cost ~15 us of host time per launch, enough to make the host the bottleneck.  The roofline figures come from the isolated
     # single-stream steps after the timed region.
-    timed = ["gemm", "wgrad_group", "attn_fwd", "attn_bwd"]
+    timed = ["gemm", "wgrad_group", "panel_gemm", "attn_fwd", "attn_bwd"]
     if a.profile_ops:
         timed += ["layernorm_fwd", "layernorm_bwd", "colsum", "bn_fwd", "bn_bwd", "embed_fwd", "embed_bwd", "posenc_fwd", "posenc_bwd", "rowmask",
                   "add_inplace", "add_strided", "specaugment", "disc_gather", "disc_scatter", "speech_loss_fwd", "speech_loss_bwd", "text_loss_fwd",
@@ -351,7 +394,7 @@ def main():
     side = config.SIDE_STREAMS
     config.SIDE_STREAMS = False
     try:
-        with OpTimer(ops, ["gemm", "wgrad_group", "attn_fwd", "attn_bwd"]) as ot_iso:
+        with OpTimer(ops, ["gemm", "wgrad_group", "panel_gemm", "attn_fwd", "attn_bwd"]) as ot_iso:
             for i in range(a.iso_steps):
                 train.train_step(losses, model, opt, sched, batches, n_prime + a.warmup + a.steps + i, args)
             sync()
@@ -374,6 +417,10 @@ def main():
             gsu = su["wgrad_group"]
             calls += sum(v[0] for v in gsu.values()); tot += sum(v[1] for v in gsu.values())
             fl += sum(group_flops(k) * v[0] for k, v in gsu.items()); by += sum(group_bytes(k) * v[0] for k, v in gsu.items())
+        if n == "gemm" and "panel_gemm" in su:       # ... and so do the row-panel launches (the same contractions on the other kernel)
+            psu = su["panel_gemm"]
+            calls += sum(v[0] for v in psu.values()); tot += sum(v[1] for v in psu.values())
+            fl += sum(panel_flops(k) * v[0] for k, v in psu.items()); by += sum(panel_bytes(k) * v[0] for k, v in psu.items())
         return dict(calls=calls, ms=tot, flops=fl, bytes=by)
     global ATTN_BWD_PRODUCTS, ATTN_BWD_KERNEL
     if not config.ATTN_FUSED_BWD:
@@ -392,33 +439,33 @@ def main():
     gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0
     gtf = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
     traffic = None
-    for tp in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for tp in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         tp = os.path.join(ROOT, "profiles", tp)
         if a.workload == "c3" and config.NSPLIT == 3 and os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                gk = [v for k, v in tj["kernels"].items() if "gemm_kernel" in k or "gemm_group" in k]
+                gk = [v for k, v in tj["kernels"].items() if "gemm_kernel" in k or "gemm_group" in k or "panel_kernel" in k]
                 traffic = round(sum(v["hbm_MB_per_launch"] * v["launches"] for v in gk) / sum(v["launches"] for v in gk) * 1e6, 0)
                 break
             except Exception:
                 traffic = None
     rocprof_avg = None           # the same family's average launch duration in the committed single-stream rocprofv3 summary
-    for cp in ("r02_f_bench_c3_single_stream_kernel_stats.csv", "r02_d_bench_c3_single_stream_kernel_stats.csv", "r02_b_bench_c3_single_stream_kernel_stats.csv"):
+    for cp in ("r03_b_bench_c3_single_stream_kernel_stats.csv", "r02_f_bench_c3_single_stream_kernel_stats.csv", "r02_d_bench_c3_single_stream_kernel_stats.csv"):
         cp = os.path.join(ROOT, "profiles", cp)
         if a.workload == "c3" and config.NSPLIT == 3 and os.path.exists(cp):
             try:
                 import csv
-                rows = [r for r in csv.DictReader(open(cp)) if r["Name"].startswith("void gemm_kernel") or "gemm_group_kernel" in r["Name"]]
+                rows = [r for r in csv.DictReader(open(cp)) if r["Name"].startswith("void gemm_kernel") or "gemm_group_kernel" in r["Name"] or "panel_kernel" in r["Name"]]
                 rocprof_avg = round(sum(int(r["TotalDurationNs"]) for r in rows) / sum(int(r["Calls"]) for r in rows) / 1e3, 2)
                 break
             except Exception:
                 rocprof_avg = None
-    roofline = {"kernel": "gemm_kernel<*,*,%d> (all linear / conv contractions: forward, dgrad, grouped wgrad)" % config.NSPLIT,
+    roofline = {"kernel": "gemm_kernel<*,*,%d> + panel_kernel<*> (all linear / conv contractions: forward, dgrad, grouped wgrad; the K <= 256 ones over >= 16 384 rows on the row-panel kernel)" % config.NSPLIT,
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": round(g["bytes"] / max(g["calls"], 1), 0),
                 "launches_per_step": g["calls"] / steps_iso, "avg_launch_us": round(g["ms"] * 1e3 / max(g["calls"], 1), 2),
                 "ms_per_step": round(g["ms"] / steps_iso, 3), "measured_over": "%d single-stream eager step(s) after the timed region" % a.iso_steps,
-                "rocprof_avg_launch_us": rocprof_avg,
+                "rocprof_avg_launch_us": rocprof_avg, "profiles_match_csrc": profiles_fresh(),
                 "mfma_view": {"achieved_tflops": round(gtf, 2), "frac_of_2500_dense_bf16": round(gtf / PEAK_MFMA_BF16_TFLOPS, 4),
                               "mfma_issue_tflops": round(gtf * config.NSPLIT, 1), "sustained_mfma_peak_measured_tflops": SUSTAINED_MFMA_TFLOPS},
                 "attn_fwd": mfma_entry("attn_fwd", "attn_q_kernel<%d,0>" % config.NSPLIT),
@@ -428,7 +475,7 @@ def main():
                         "timed region (inside the timed region a launch shares the chip with the kernels of the other three streams, and a replayed "
                         "capture has no per-kernel host hooks); traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE per launch "
                         "from profiles/ (separate rocprofv3 passes of this command), null if absent; rocprof_avg_launch_us = the family's average kernel "
-                        "duration in the committed single-stream rocprofv3 summary (profiles/r02_f_*): avg_launch_us brackets each launch with a "
+                        "duration in the committed single-stream rocprofv3 summary (profiles/r03_b_* or the newest older one; profiles_match_csrc says whether csrc/ still is what that summary was taken from): avg_launch_us brackets each launch with a "
                         "HIP-event pair and so carries ~4 us of dispatch per launch on top of it; mfma_view / attn_*: 2MNK FLOPs per "
                         "contraction, 4*B*H*Tq*Tk*64 per attention forward (x2.5 backward, causal at T(T+1)/2); each product costs %d bf16 MFMAs in "
                         "%s mode; sustained MFMA peak = tools/mfma_peak.cpp on this chip" % (config.NSPLIT, a.precision)}

@@ -287,8 +287,7 @@ __global__ __launch_bounds__(128 * (4 / QS), (QS == 1 ? 4 : 2)) void attn_q_kern
                             }
                             tmax = fmaxf(tmax, v);
                         }
-                    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                    tmax = rows4_max(tmax);
                     const float mnew = fmaxf(m[qs], tmax * ssc);
                     const float alpha = __builtin_amdgcn_exp2f(m[qs] - mnew);
                     m[qs] = mnew;
@@ -328,9 +327,7 @@ __global__ __launch_bounds__(128 * (4 / QS), (QS == 1 ? 4 : 2)) void attn_q_kern
                     }
                 }
                 if (MODE == 0) {
-                    rs += __shfl_xor(rs, 16, 64);
-                    rs += __shfl_xor(rs, 32, 64);
-                    lsum[qs] += rs;
+                    lsum[qs] += rows4_sum(rs);
                 }
             }
         };

@@ -61,7 +61,9 @@ __device__ __forceinline__ uint32_t rng_u32(uint32_t row_key, uint32_t col) { re
 // already well-mixed per-row key.  thresh = p * 2^16 (0 => keep everything).  All kernels (GEMM epilogue, LayerNorm
 // backward, attention forward/backward, element-wise) use these two helpers, so masks agree across passes.
 __device__ __forceinline__ uint32_t rng_pair(uint32_t row_key, uint32_t col) {
-    uint32_t h = ((col >> 1) ^ row_key) * 0x9E3779B1u;
+    // 24-bit multiply (v_mul_u32_u24, full rate; a 32-bit v_mul_lo_u32 issues at a quarter of it -- 16 cycles -- and the attention kernels
+    // draw one of these per pair of scores): the low 24 bits of the already well-mixed per-row key, xor the column pair, times an odd constant
+    uint32_t h = __umul24((col >> 1) ^ row_key, 0x9E3779u);
     return h ^ (h >> 15);
 }
 __device__ __forceinline__ bool rng_keep_lo(uint32_t pair_hash, uint32_t thresh) { return (pair_hash & 0xFFFFu) >= thresh; }
@@ -134,6 +136,25 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
 // ---------------------------------------------------------------------------------------------
 // Wave / block reductions
 // ---------------------------------------------------------------------------------------------
+// Reductions over the four 16-lane rows of a wave (lanes that differ in bits 4 and 5) without the LDS crossbar: gfx950's
+// v_permlane16_swap exchanges the odd rows of one register with the even rows of another, v_permlane32_swap the upper half of one with
+// the lower half of the other -- fed the same value twice they return {partner's value, own value} pairs, i.e. an xor-16 / xor-32
+// butterfly in two vector instructions instead of a ds_bpermute round trip (~100 cycles of latency on the softmax's dependent chain).
+__device__ __forceinline__ float rows4_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    float x = __uint_as_float(a[0]), y = __uint_as_float(a[1]);
+    asm("v_max_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));                 // (fmaxf would add a canonicalising v_max per operand)
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    float z = __uint_as_float(b[0]), w = __uint_as_float(b[1]);
+    asm("v_max_f32 %0, %1, %2" : "=v"(z) : "v"(z), "v"(w));
+    return z;
+}
+__device__ __forceinline__ float rows4_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
