@@ -188,6 +188,9 @@ int unast_disc_gather(const float* t_hid, const float* s_hid, const int* t_len, 
 int unast_disc_scatter(const float* dout, const int64_t* perm, float* dt_hid, float* ds_hid, int B, int Tt, int Ts, int D,
                        hipStream_t stream);
 
+/* masked_mse (src/train.py:100-103) on its own: out[0] = sum((gold - pred)^2 * mask) / sum(mask) over n elements.  ws3: three
+ * doubles of workspace, zero on entry, left zero on exit.  (The train step's two masked MSEs come out of unast_speech_loss_*.) */
+int unast_masked_mse(const float* gold, const float* pred, const float* mask, int64_t n, double* ws3, float* out, hipStream_t stream);
 /* speech_loss (src/train.py:100-103, 113-122): head = [pre-net mel (M cols) | stop logit | pad] with row stride ldh.
  * fwd writes loss[0]; bwd writes d_head (same layout) and d_post scaled by the device scalar *gscale. ws: 3 doubles. */
 int unast_speech_loss_fwd(const float* gold, const float* head, int ldh, const float* post, const int* lens, int B, int T, int M,

@@ -276,3 +276,21 @@ def test_compute_d_score():
     out = torch.tensor([2.0, -1.0, 0.3, -0.2])
     tgt = torch.tensor([0.9, 0.1, 0.1, 0.9])
     assert int(compute_d_score(out, tgt)) == 2
+
+
+def test_replay_planner_under_address_sanitizer(tmp_path):
+    """csrc/graph_layout.h (the stream layout of the replay executor, csrc/graph_exec.cpp) on synthetic DAGs, built for the CPU with
+    -fsanitize=address,undefined: every dependency ordered by stream order or a record/wait pair, records issued ahead of their waits."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gxx = shutil.which("g++")
+    assert gxx, "g++ is part of the image"
+    exe = str(tmp_path / "test_graph_layout")
+    subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=all",
+                    "-o", exe, os.path.join(root, "tests", "native", "test_graph_layout.cpp")], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all cases passed" in r.stdout
+    src = open(os.path.join(root, "unast_amd", "csrc", "graph_exec.cpp")).read()
+    assert "unast_layout::plan_layout" in src, "the executor must plan through the tested header"

@@ -77,3 +77,56 @@ def test_eval_mode_backward_is_refused():
     (text, mel, tl, ml), _ = train.process_batch(batch)
     with pytest.raises(NotImplementedError):
         model.text_ae(text, tl)
+
+
+def test_single_step_decode_postprocess_and_masked_mse():
+    """The reference's uncached surfaces (src/network.py:210-217, 446-453; src/train.py:100-103): decode() = last position of the
+    teacher-forced decoder fed the same inputs, postprocess() = the post-net alone, masked_mse = its formula."""
+    from unast_amd import train
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_b3_t12_m40_l2_s77.npz"))
+    args, model, nb = build(g["meta"])
+    model.eval()
+    batch = tuple(torch.from_numpy(g["b0/%s" % k]) for k in ("text", "mel", "text_len", "mel_len"))
+    (text, mel, tl, ml), _ = train.process_batch(batch)
+    B, Tm, M = mel.shape
+    with torch.no_grad():
+        s_enc, s_masks = model.speech_m.encode(mel, ml)
+        pre, post, stop, _ = model.speech_m.decode_sequence(mel, ml, s_enc, s_masks)
+        # speech: decoder input of decode_sequence is [zero frame, mel[:-1]]; decode() takes it as it is
+        tgt = torch.zeros_like(mel); tgt[:, 1:] = mel[:, :-1]
+        full = torch.full((B,), Tm, dtype=torch.int32, device=D)
+        pad = torch.zeros(B, Tm, dtype=torch.bool, device=D)
+        enc_pad = torch.arange(Tm, device=D)[None, :] >= ml.to(D)[:, None]
+        mel_last, stop_last = model.speech_m.decode(tgt, full, pad, s_enc, enc_pad)
+        assert mel_last.shape == (B, 1, M) and stop_last.shape == (B, 1, 1)
+        # rows whose own length is Tm see exactly what decode_sequence saw (it masks keys past each row's length)
+        rows = (ml.to(D) == Tm).nonzero().flatten()
+        assert rows.numel() > 0
+        assert torch.allclose(mel_last[rows, 0], pre[rows, -1], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(stop_last[rows, 0, 0], stop[rows, -1], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(model.speech_m.postprocess(pre), post - pre, rtol=1e-4, atol=2e-5)
+        # text
+        t_enc, t_masks = model.text_m.encode(text, tl)
+        logits = model.text_m.decode_sequence(text, tl, t_enc, t_masks)
+        Tt = text.shape[1]
+        tin = torch.cat([torch.full((B, 1), 1, dtype=text.dtype, device=text.device), text[:, :-1]], dim=1)      # [SOS, text[:-1]]
+        tpad = torch.zeros(B, Tt, dtype=torch.bool, device=D)
+        last = model.text_m.decode(tin, tl, tpad, t_enc, t_masks[1])
+        rows = (tl.to(D) == Tt).nonzero().flatten()
+        assert last.shape == (B, 1, logits.shape[-1]) and rows.numel() > 0
+        assert torch.allclose(last[rows, 0], logits[rows, -1], rtol=1e-4, atol=1e-5)
+        hid = torch.randn(B, 5, 256, device=D)
+        W, b = model.text_m.postnet.fc1.weight, model.text_m.postnet.fc1.bias
+        want = (hid.double() @ W.double().t() + b.double()).float()
+        assert torch.allclose(model.text_m.postprocess(hid), want, rtol=1e-4, atol=1e-4)
+        with pytest.raises(ValueError):
+            bad = pad.clone(); bad[0, 1] = True
+            model.speech_m.decode(tgt, full, bad, s_enc, enc_pad)
+    # masked_mse
+    torch.manual_seed(0)
+    gold, pred = torch.randn(3, 40, 80, device=D), torch.randn(3, 40, 80, device=D)
+    mask = (torch.arange(40, device=D)[None, :, None] < torch.tensor([40, 17, 5], device=D)[:, None, None]).float().repeat(1, 1, 80)
+    want = (((gold.double() - pred.double()) ** 2) * mask.double()).sum() / mask.double().sum()
+    for _ in range(2):                                                      # the workspace must come back zeroed
+        got = train.masked_mse(gold, pred, mask)
+        assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))

@@ -248,6 +248,33 @@ def test_full_batch_step_is_reproducible_and_finite():
         assert abs(res[0][k] - res[1][k]) <= 2e-5 * max(1.0, abs(res[0][k])), (k, res[0][k], res[1][k])
 
 
+def test_config5_full_batch_step_is_reproducible_and_finite():
+    """BASELINE.json config 5 as a step, not only per kernel: B=32, T_mel=2000 (64 000 rows per speech GEMM, 2000x2000 causal
+    attention, 2000-step recurrences), the complete step twice from the same state and seed."""
+    from collections import defaultdict
+    from unast_amd import train, utils
+    from unast_amd.portable import synth_batch
+    res = []
+    for rep in range(2):
+        args, model, opt, sd = build(4, 1e-3)
+        utils.set_deterministic(False)
+        try:
+            utils.set_seed(5)
+            batch = tuple(torch.from_numpy(x) for x in synth_batch(B, TT, 2000, seed=2, ragged=True))
+            batches = dict(unsup=[batch], sup=[batch], disc=[batch], cm=[])
+            losses = defaultdict(list)
+            train.train_step(losses, model, opt, None, batches, 1, args)
+            res.append({k: float(v[-1]) for k, v in losses.items()})
+            assert all(v == v and abs(v) < 1e4 for v in res[-1].values()), res[-1]
+            assert bool(torch.isfinite(model._store().flat).all())
+        finally:
+            utils.set_deterministic(True)
+        del model, opt
+        torch.cuda.empty_cache()
+    for k in res[0]:
+        assert abs(res[0][k] - res[1][k]) <= 2e-5 * max(1.0, abs(res[0][k])), (k, res[0][k], res[1][k])
+
+
 def test_deferred_discriminator_phase_matches_joined():
     """train_step(defer_d_phase=True) (the D phase stays on its own stream and overlaps the next step's generator forward, as
     train() and bench.py run it) reaches the same losses as the default, fully joined, form over several consecutive steps.

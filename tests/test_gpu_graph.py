@@ -183,7 +183,8 @@ def test_graph_replay_with_alternating_input_shapes():
                 else:
                     train.train_step(losses, model, opt, None, b, i, args, defer_d_phase=True)
             if graphed:
-                assert len(stepper.graphs) == 2 and len(stepper.static_by_sig) == 2
+                assert len(stepper.graphs) == 2 and len(stepper.static_gen) == 2 and len(stepper.static_disc) == 2
+                assert stepper.stats["captures"] == 2 and stepper.stats["replays"] == 6 and stepper.stats["evictions"] == 0, stepper.stats
                 stepper.flush(losses)
             join_streams(); torch.cuda.synchronize()
         finally:
@@ -205,3 +206,71 @@ def test_odd_shapes_and_step_layouts_eager_vs_replay():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_shapes.py")], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert out.returncode == 0 and b"stress ok" in out.stdout, out.stdout.decode()[-3000:]
 
+
+
+class _ShapedBatches:
+    """Batch getter whose batches follow a list of (B, T_text, T_mel) shapes, one entry per outer step (ae 1, sp 1, d 1)."""
+
+    def __init__(self, shapes):
+        self.shapes, self.calls = shapes, 0
+
+    def _next(self):
+        from unast_amd.portable import synth_batch
+        B, Tt, Tm = self.shapes[(self.calls // 3) % len(self.shapes)]
+        self.calls += 1
+        return tuple(torch.from_numpy(x) for x in synth_batch(B, Tt, Tm, seed=self.calls, ragged=True))
+
+    get_supervised_batch = get_unsupervised_batch = get_discriminator_batch = _next
+
+
+def test_twelve_shapes_through_train_are_captured_once_each():
+    """train(use_hip_graphs=True) over a loader with twelve distinct padded shapes in runs of three steps, two passes: every pair of
+    shapes met twice is captured exactly once and stays cached (no eviction, no re-capture), later meetings replay."""
+    from unast_amd import train, utils
+    from unast_amd.configs import make_args
+    shapes = [(3, 8 + 2 * i, 32 + 8 * i) for i in range(12)]
+    seq = [s for _ in range(2) for s in shapes for _ in range(3)]
+    utils.set_deterministic(False)
+    train.DEVICE = D
+    args = make_args(num_layers=2, ae_steps=1, sp_steps=1, d_steps=1, cm_steps=0, epochs=1, epoch_steps=len(seq), use_hip_graphs=True, train_batch_size=3)
+    model, hist = train.train(args, batch_getter=_ShapedBatches(seq))
+    rep = model.__dict__["_graph_stepper"].cache_report()
+    assert all(v == v for v in hist[0].values())
+    # 71 bodies (the first step has none).  Pass 1: per run one cross pair (eager) and the same-shape pair twice (eager, then capture +
+    # replay); pass 2: the pair (last shape, first shape) is new (eager), the 11 other cross pairs are met again (captured), same-shape
+    # pairs replay
+    assert rep["evictions"] == 0 and rep["captures"] == rep["cached"] == 12 + 11, rep
+    assert rep["shapes_gen"] == 12 and rep["shapes_disc"] == 12, rep
+    assert rep["eager_bodies"] == 12 + 11 + 1, rep
+    assert rep["replays"] == 71 - 24, rep
+    sigs = [(c["disc_shapes"], c["gen_shapes"]) for c in rep["per_capture"]]
+    assert len(set(sigs)) == len(sigs)
+    assert all(c["capture_ms"] > 0 and c["replays"] >= 1 for c in rep["per_capture"])
+
+
+def test_lru_keeps_the_hot_shape_while_cold_ones_pass_through(monkeypatch):
+    """Four cached captures, one hot shape met between runs of five cold ones: the hot capture is never evicted nor re-captured (a
+    first-in-first-out cache would drop it after four cold captures)."""
+    import unast_amd.graphed as G
+    from unast_amd import utils
+    monkeypatch.setattr(G, "MAX_GRAPHS", 4)
+    hot = (3, 12, 40)
+    seq = [hot] * 4
+    for i in range(5):
+        seq += [(2, 8 + 2 * i, 48 + 8 * i)] * 3 + [hot] * 3
+    utils.set_deterministic(False)
+    args, model, opt, sched = build(2, 1e-7)
+    stepper = G.GraphedTrainStep(model, opt, None, args)
+    captured = []
+    real = stepper._capture
+    monkeypatch.setattr(stepper, "_capture", lambda sig: (captured.append(sig), real(sig))[1])
+    losses = defaultdict(list)
+    for i, (B, Tt, Tm) in enumerate(seq):
+        stepper(losses, batches_for(i, B, Tt, Tm), i)
+    stepper.flush(losses)
+    torch.cuda.synchronize()
+    hot_sig = [s for s in captured if s[0][0][2][1] == (hot[0], hot[2], 80) and s[1][0][2][1] == (hot[0], hot[2], 80)]
+    assert len(hot_sig) == 1, captured
+    assert len(captured) == len(set(captured)), "a capture still cached was made again"
+    assert stepper.stats["evictions"] >= 1 and len(stepper.graphs) <= 4 and hot_sig[0] in stepper.graphs, stepper.stats
+    assert all(np.isfinite([float(x) for x in v]).all() for v in losses.values())

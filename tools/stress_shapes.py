@@ -12,7 +12,9 @@ from unast_amd.portable import synth_batch
 D = torch.device("cuda:0"); train.DEVICE = D
 
 
-def run(graphed, shapes, **kw):
+def run(graphed, shapes, max_graphs=None, **kw):
+    import unast_amd.graphed as G
+    G.MAX_GRAPHS = max_graphs or 32
     utils.set_seed(0); utils.set_deterministic(True)
     args = make_args(num_layers=2, cm_steps=0, lr=1e-7, **kw)
     _, _, model, opt, sched = train.initialize_model(args)
@@ -28,6 +30,8 @@ def run(graphed, shapes, **kw):
             train.train_step(losses, model, opt, None, b, i, args, defer_d_phase=True)
     if graphed:
         stepper.flush(losses)
+        if max_graphs:
+            assert stepper.stats["evictions"] > 0 and len(stepper.graphs) <= max_graphs, stepper.stats
     join_streams(); torch.cuda.synchronize()
     return {k: [float(x) for x in v] for k, v in losses.items()}
 
@@ -47,7 +51,8 @@ def check(name, shapes, **kw):
 check("tiny lengths (T_text 3, T_mel 7)", [(2, 3, 7)] * 5)
 check("batch 1, odd lengths", [(1, 17, 33)] * 5)
 check("lengths not multiples of 16", [(3, 21, 131)] * 5)
-check("six signatures (> cached captures)", [(2, 8 + 4 * (i % 6), 32 + 16 * (i % 6)) for i in range(24)])
+check("six signatures in turn (six shape pairs)", [(2, 8 + 4 * (i % 6), 32 + 16 * (i % 6)) for i in range(24)])
+check("six signatures, three cached captures (eviction)", [(2, 8 + 4 * (i % 6), 32 + 16 * (i % 6)) for i in range(30)], max_graphs=3)
 check("accumulation: ae 2, sp 2, d 2", [(2, 12, 40)] * 5, ae_steps=2, sp_steps=2, d_steps=2)
 check("generator only", [(2, 12, 40)] * 5, use_discriminator=False)
 print("stress ok")

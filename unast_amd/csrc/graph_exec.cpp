@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 #include "common.h"
+#include "graph_layout.h"
 #include "../../include/unast_hip.h"
 
 namespace {
@@ -59,7 +60,7 @@ extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
     if (hipGraphGetNodes(graph, nodes.data(), &n) != hipSuccess) { unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: hipGraphGetNodes failed"); return 0; }
     std::map<hipGraphNode_t, int> index;
     for (size_t i = 0; i < n; ++i) index[nodes[i]] = (int)i;
-    std::vector<std::vector<int>> deps(n), succ(n);
+    std::vector<std::vector<int>> deps(n);
     for (size_t i = 0; i < n; ++i) {
         size_t nd = 0;
         if (hipGraphNodeGetDependencies(nodes[i], nullptr, &nd) != hipSuccess) { unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: hipGraphNodeGetDependencies failed"); return 0; }
@@ -70,70 +71,29 @@ extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
                 auto it = index.find(d[j]);
                 if (it == index.end()) { unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: dependency outside the graph"); return 0; }
                 deps[i].push_back(it->second);
-                succ[it->second].push_back((int)i);
             }
         }
     }
-    // topological order, smallest creation index first (capture order is one; do not rely on it)
-    std::vector<int> indeg(n), order;
-    order.reserve(n);
+    // ---- lay the DAG out on streams (graph_layout.h: pure host logic, unit-tested on the CPU under AddressSanitizer) -----------------
+    unast_layout::Layout lay;
     {
-        std::vector<int> ready;
-        for (size_t i = 0; i < n; ++i) { indeg[i] = (int)deps[i].size(); if (!indeg[i]) ready.push_back((int)i); }
-        std::make_heap(ready.begin(), ready.end(), std::greater<int>());
-        while (!ready.empty()) {
-            std::pop_heap(ready.begin(), ready.end(), std::greater<int>());
-            const int v = ready.back(); ready.pop_back();
-            order.push_back(v);
-            for (int s : succ[v]) if (--indeg[s] == 0) { ready.push_back(s); std::push_heap(ready.begin(), ready.end(), std::greater<int>()); }
-        }
-        if (order.size() != n) { unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: graph has a cycle"); return 0; }
+        std::string err;
+        if (!unast_layout::plan_layout((int)n, deps, nstreams, lay, err)) { unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: %s", err.c_str()); return 0; }
     }
     Plan* plan = new Plan();
-    // ---- lay the DAG out on streams -------------------------------------------------------------------------------------------
-    std::vector<int> stream_of(n, -1), tail(nstreams, -1), remaining(n);          // remaining: successors not yet placed
-    std::vector<long long> last_use(nstreams, -1);
-    std::vector<int> needs_event(n, 0), event_of(n, -1);
-    for (size_t i = 0; i < n; ++i) remaining[i] = (int)succ[i].size();
-    std::vector<std::vector<int>> waited(nstreams, std::vector<int>(nstreams, -1));   // waited[s][t] = position of the newest node of stream t that s has waited for
-    std::vector<int> pos_in_order(n, 0);
+    plan->events.assign(lay.event_node.size(), nullptr);
+    plan->cross_edges = lay.cross_edges;
     std::vector<PlanOp> ops;
-    long long tick = 0;
-    for (size_t oi = 0; oi < n; ++oi) {
-        const int v = order[oi];
-        pos_in_order[v] = (int)oi;
+    ops.reserve(lay.ops.size());
+    for (const unast_layout::LayoutOp& lo : lay.ops) {
+        if (lo.kind == unast_layout::L_WAIT || lo.kind == unast_layout::L_RECORD) {
+            PlanOp w{}; w.kind = lo.kind == unast_layout::L_WAIT ? OP_WAIT : OP_RECORD; w.stream = lo.stream; w.event = lo.id;
+            ops.push_back(w);
+            continue;
+        }
+        const int v = lo.id, s = lo.stream;
         hipGraphNodeType type;
         if (hipGraphNodeGetType(nodes[v], &type) != hipSuccess) { unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: hipGraphNodeGetType failed"); return 0; }
-        // stream: continue behind a dependency that is still the tail of its stream (the newest such), else the stream whose branch has
-        // ended (its tail has no unplaced successors) or, failing that, the least recently used one
-        int s = -1, best = -1;
-        for (int d : deps[v]) {
-            const int sd = stream_of[d];
-            if (tail[sd] == d && pos_in_order[d] > best) { best = pos_in_order[d]; s = sd; }
-        }
-        if (s < 0) {
-            for (int t = 0; t < nstreams && s < 0; ++t) if (tail[t] < 0) s = t;
-            if (s < 0) {
-                long long lru = -1;
-                for (int t = 0; t < nstreams; ++t)
-                    if (remaining[tail[t]] == 0 && (s < 0 || last_use[t] < lru)) { s = t; lru = last_use[t]; }
-            }
-            if (s < 0) {
-                long long lru = 0;
-                for (int t = 0; t < nstreams; ++t) if (s < 0 || last_use[t] < lru) { s = t; lru = last_use[t]; }
-            }
-        }
-        for (int d : deps[v]) {
-            --remaining[d];
-            const int sd = stream_of[d];
-            if (sd == s) continue;                                   // stream order covers it (d was placed earlier on the same stream)
-            if (waited[s][sd] >= pos_in_order[d]) continue;          // already behind a later node of that stream
-            if (event_of[d] < 0) { event_of[d] = (int)plan->events.size(); plan->events.push_back(nullptr); needs_event[d] = 1; }
-            PlanOp w{}; w.kind = OP_WAIT; w.stream = s; w.event = event_of[d];
-            ops.push_back(w);
-            waited[s][sd] = pos_in_order[d];
-            ++plan->cross_edges;
-        }
         PlanOp op{};
         op.stream = s;
         if (type == hipGraphNodeTypeKernel) {
@@ -173,17 +133,6 @@ extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
             unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: unsupported node type %d (node %d)", (int)type, v); return 0;
         }
         ops.push_back(op);
-        // the record for cross-stream consumers is emitted right behind the node; whether it is needed is known only later, so every
-        // node gets a slot and unused ones are dropped below
-        PlanOp r{}; r.kind = OP_RECORD; r.stream = s; r.event = v;   // event index patched below (v = node index for now)
-        ops.push_back(r);
-        stream_of[v] = s; tail[s] = v; last_use[s] = ++tick;
-    }
-    for (auto& op : ops) {
-        if (op.kind == OP_RECORD) {
-            if (!needs_event[op.event]) { op.kind = -2; continue; }
-            op.event = event_of[op.event];
-        }
     }
     for (auto& op : ops) if (op.kind >= 0) plan->ops.push_back(op);
     // streams, events

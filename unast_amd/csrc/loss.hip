@@ -257,4 +257,42 @@ extern "C" int unast_bce_logits(const float* logits, int ldx, const float* targe
     return unast_check_launch("unast_bce_logits");
 }
 
+// masked_mse (src/train.py:100-103) as its own entry: sum((gold - pred)^2 * mask) / sum(mask).  One launch: every workgroup adds its
+// two fp64 partial sums into ws[0..1] and counts itself in ws[2]; the last one to arrive divides (ws must be zero on entry and is
+// left zero again, so one workspace serves call after call).
+__global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ gold, const float* __restrict__ pred, const float* __restrict__ mask,
+                                                         size_t n, double* __restrict__ ws, float* __restrict__ out) {
+    double num = 0.0, den = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = gold[i] - pred[i], m = mask[i];
+        num += (double)(d * d * m);
+        den += (double)m;
+    }
+    num = wave_sum_d(num);
+    den = wave_sum_d(den);
+    __shared__ double sn[4], sd[4];
+    if ((threadIdx.x & 63) == 0) { sn[threadIdx.x >> 6] = num; sd[threadIdx.x >> 6] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(ws + 0, (sn[0] + sn[1]) + (sn[2] + sn[3]));
+        atomicAdd(ws + 1, (sd[0] + sd[1]) + (sd[2] + sd[3]));
+        __threadfence();
+        const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long*>(ws + 2), 1ull) + 1ull;
+        if (arrived == gridDim.x) {
+            __threadfence();
+            const double a = atomicAdd(ws + 0, 0.0), b = atomicAdd(ws + 1, 0.0);
+            out[0] = (float)(a / b);
+            ws[0] = 0.0; ws[1] = 0.0; reinterpret_cast<unsigned long long*>(ws)[2] = 0ull;
+        }
+    }
+}
+
+extern "C" int unast_masked_mse(const float* gold, const float* pred, const float* mask, int64_t n, double* ws3, float* out, hipStream_t stream) {
+    UNAST_REQUIRE(gold && pred && mask && ws3 && out && n > 0, "unast_masked_mse: bad arguments");
+    size_t blocks = ((size_t)n + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(masked_mse_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, gold, pred, mask, (size_t)n, ws3, out);
+    return unast_check_launch("unast_masked_mse");
+}
+
 UNAST_DEFINE_RNG_EPOCH_SETTER(loss)

@@ -337,12 +337,13 @@ def text_encode(cx, tape, m, ids, lens, noise):
     return encoder_stack(cx, tape, x, lens, "text_m.encoder.transformer_encoder.layers.", a.num_layers, B, T, a.nhead, a.e_drop)
 
 
-def text_decode(cx, tape, m, ids, lens_q, mem, lens_k, Tk):
+def text_decode(cx, tape, m, ids, lens_q, mem, lens_k, Tk, shift=True):
     """TextTransformer.decode_sequence (src/network.py:483-493) incl. TextPostnet (src/module.py:233-246).
-    Returns Var logits buffer [B*T, 48] (46 valid columns)."""
+    Returns Var logits buffer [B*T, 48] (46 valid columns).  shift=False: `ids` are the decoder inputs as they are
+    (TextTransformer.decode, src/network.py:446-450)."""
     B, T = ids.shape
     a = m.args
-    x = text_embed(cx, tape, ids, T, a.t_pre_drop, False, 1)          # SOS_IDX = 1
+    x = text_embed(cx, tape, ids, T, a.t_pre_drop, False, 1 if shift else -1)          # SOS_IDX = 1
     x = posenc(cx, tape, x, m.pe, T)
     x = decoder_stack(cx, tape, x, lens_q, mem, lens_k, "text_m.decoder.transformer_decoder.layers.", a.num_layers, B, T, Tk, a.nhead, a.d_drop)
     N, E = x.v.shape
@@ -427,14 +428,19 @@ def speech_encode(cx, tape, m, mel, lens, noise):
     return encoder_stack(cx, tape, x, lens, "speech_m.encoder.transformer_encoder.layers.", a.num_layers, B, T, a.nhead, a.e_drop)
 
 
-def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk):
+def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk, shift=True, postnet=True):
     """SpeechTransformer.decode_sequence (src/network.py:254-269) + SpeechPostnet (src/module.py:155-171).
-    Returns (head Var [B*T, 84]: cols 0..79 pre-net mel, col 80 stop logit; post Var [B*T, 80])."""
+    Returns (head Var [B*T, 84]: cols 0..79 pre-net mel, col 80 stop logit; post Var [B*T, 80]).
+    shift=False feeds `mel` as the decoder input as it is, postnet=False stops at the heads (SpeechTransformer.decode,
+    src/network.py:210-214; no tape)."""
     B, T, M = mel.shape
     a = m.args
     N = B * T
-    tgt = torch.zeros_like(mel)                                    # [zero frame, mel[:-1]]  (device-memory plumbing)
-    tgt[:, 1:] = mel[:, :-1]
+    if shift:
+        tgt = torch.zeros_like(mel)                                # [zero frame, mel[:-1]]  (device-memory plumbing)
+        tgt[:, 1:] = mel[:, :-1]
+    else:
+        tgt = mel.contiguous()
     x = speech_prenet(cx, tape, m, tgt.view(N, M), T)
     x = decoder_stack(cx, tape, x, lens_q, mem, lens_k, "speech_m.decoder.transformer_decoder.layers.", a.num_layers, B, T, Tk, a.nhead, a.d_drop)
     E = x.v.shape[1]
@@ -464,6 +470,8 @@ def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk):
             ops.linear_dgrad(dh[:, :M + 1], Wh, dx)
             acc(x, dx)
         tape.record(bwd_head)                                       # runs after every postnet closure
+    if not postnet:
+        return headv, None
     pool = ZeroPool(4, cx.P["speech_m.postnet.conv1.conv.weight"].shape[0], mel.device) if cx.training else None
     y = conv_bn_act(cx, tape, pre, B, T, "speech_m.postnet.conv1.", "speech_m.postnet.pre_batchnorm.", 4, 2, a.s_post_drop, m.buffers_dict, pool=pool)
     for i in range(3):
@@ -625,8 +633,27 @@ def speech_prenet_step(cx, m, frames, pos_t):
     return h2
 
 
-def speech_postnet_residual(cx, m, mel3d):
-    """mel + SpeechPostnet(mel) for a [B,T,M] tensor (src/network.py:246; BN in the model's current mode)."""
+def text_postnet(cx, m, hid3d):
+    """TextPostnet (src/module.py:233-246) on a [B,T,E] tensor: fc1(dropout(x)) -> [B,T,V]; no tape."""
+    B, T, E = hid3d.shape
+    N = B * T
+    x = hid3d.reshape(N, E)
+    p = cx.p(m.args.t_post_drop)
+    if p > 0:
+        xd = _empty(N, E, like=x)
+        ops.leaky_dropout(x, None, xd, 1.0, drop_p=p, seed=cx.seed, stream_id=cx.stream())
+        x = xd
+    W, b = cx.P["text_m.postnet.fc1.weight"], cx.P["text_m.postnet.fc1.bias"]
+    V = W.shape[0]
+    ldl = (V + 3) // 4 * 4
+    logits = torch.zeros(N, ldl, dtype=torch.float32, device=x.device)
+    ops.linear_fwd(x, W, b, logits[:, :V])
+    return logits.view(B, T, ldl)[..., :V]
+
+
+def speech_postnet_residual(cx, m, mel3d, residual=True):
+    """mel + SpeechPostnet(mel) for a [B,T,M] tensor (src/network.py:246; BN in the model's current mode); residual=False:
+    SpeechPostnet(mel) alone (SpeechTransformer.postprocess, src/network.py:216-217).  No tape."""
     B, T, M = mel3d.shape
     a = m.args
     N = B * T
@@ -638,5 +665,5 @@ def speech_postnet_residual(cx, m, mel3d):
     Wp2, b2 = cx.P["speech_m.postnet.conv2.conv.weight"], cx.P["speech_m.postnet.conv2.conv.bias"]
     post = _empty(B, T, M, like=mel3d)
     C = y.v.shape[1]
-    ops.gemm(ops.OP_KC_CONV, ops.OP_KC, y.v, C, Wp2, 5 * C, post, M, N, M, 5 * C, conv=(T, C, 0, 4), bias=b2, R=x.v, ldr=M)
+    ops.gemm(ops.OP_KC_CONV, ops.OP_KC, y.v, C, Wp2, 5 * C, post, M, N, M, 5 * C, conv=(T, C, 0, 4), bias=b2, R=x.v if residual else None, ldr=M)
     return post

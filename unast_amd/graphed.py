@@ -20,10 +20,21 @@ a graph cannot leave work behind, so the captured unit is the SHIFTED step  [ D 
 step k ]  with the same dependencies (D update before the generator's own D call, all on the discriminator's stream; generator
 update after everything).  The first call runs its generator phase eagerly, `flush()` runs the last pending D phase.
 
-Not capturable, falls back to train.train_step: cm_steps > 0 (data-dependent autoregressive generation) and an initialised
-torch.distributed group (collectives stay eager: unast_amd.ddp).
+Variable input shapes: the captured unit reads the discriminator batch of step k-1 and the generator batches of step k, so a capture
+is keyed by BOTH shapes (and the mode flags); static input buffers are kept per shape and shared by the captures that read them.
+Captures live in an LRU (MAX_GRAPHS entries, UNAST_MAX_GRAPHS) and allocate from ONE private memory pool -- replays never overlap
+and leave nothing alive but their loss vector, so the pool holds the largest step's working set once, not once per capture.  A
+(shape, shape) pair is run eagerly the first time it is met and captured the second time (a pair met once costs nothing extra);
+`cache_report()` gives captures / replays / evictions and the measured capture cost against the host time a replay saves.
+Shapes must be the batch's own padded shapes: padding batches up to a bucket changes the result (BatchNorm statistics and the stop
+loss see the pad rows).
+
+Not capturable, falls back to train.train_step: cm_steps > 0 (data-dependent autoregressive generation); under a torch.distributed
+group only with the C ABI's own RCCL communicator (ddp.native_comm), else the eager step with unast_amd.ddp.
 """
-from collections import defaultdict
+import os
+import time
+from collections import OrderedDict, defaultdict
 
 import torch
 
@@ -32,19 +43,20 @@ from . import train as T
 from .engine import join_streams
 from .utils import is_deterministic
 
-MAX_GRAPHS = 4
+MAX_GRAPHS = int(os.environ.get("UNAST_MAX_GRAPHS", "32"))
+MAX_WARMED = 4096            # (shape, shape) pairs remembered as "met once"
 
 
 class _Captured:
-    __slots__ = ("graph", "loss_keys", "loss_vec", "ranges", "plan", "plan_info")
+    __slots__ = ("graph", "loss_keys", "loss_vec", "ranges", "plan", "plan_info", "capture_ms", "replays", "replay_host_ms")
 
 
 # Replay of a captured step: "streams" = the captured nodes re-issued on ordinary HIP streams by csrc/graph_exec.cpp,
 # "hipgraph" = hipGraphLaunch of the instantiated graph, "auto" = by the shape of the graph: hipGraphLaunch is the cheaper
 # launch for a nearly linear graph (config 2, no discriminator: 16 cross-stream edges, 9.7 vs 10.5 ms/step) and the slower
 # executor for a heavily forked one (config 3: 190 cross-stream edges, 35-39 vs 32 ms/step).  MI355X, ROCm 7.2.
-REPLAY = __import__("os").environ.get("UNAST_GRAPH_REPLAY", "auto")
-REPLAY_STREAMS = int(__import__("os").environ.get("UNAST_GRAPH_REPLAY_STREAMS", "4"))       # 32.2 / 34.1 / 35.1 / 35.6 ms/step with 4 / 5 / 6 / 8 at config 3
+REPLAY = os.environ.get("UNAST_GRAPH_REPLAY", "auto")
+REPLAY_STREAMS = int(os.environ.get("UNAST_GRAPH_REPLAY_STREAMS", "4"))       # 32.2 / 34.1 / 35.1 / 35.6 ms/step with 4 / 5 / 6 / 8 at config 3
 AUTO_MIN_CROSS_EDGES = 64
 
 
@@ -55,12 +67,16 @@ class GraphedTrainStep:
         if not isinstance(optimizer, T.FusedAdamW):
             raise TypeError("GraphedTrainStep needs the FusedAdamW built by train.initialize_model")
         self.model, self.opt, self.sched, self.args = model, optimizer, scheduler, args
-        self.static = None            # {"unsup": [...], "sup": [...], "disc": [...]} of 4-tuples of device tensors (of the current signature)
-        self.static_by_sig = {}       # a capture reads the buffers it was recorded with: one set per input signature, kept with its graph
-        self.sig = None
-        self.graphs = {}              # signature -> _Captured
+        self.static = {}              # {"unsup": [...], "sup": [...], "disc": [...]} of 4-tuples of device tensors: what the next body reads
+        self.static_gen = {}          # generator-side shapes -> {"unsup": [...], "sup": [...]}
+        self.static_disc = {}         # discriminator batch shapes -> [...]
+        self.gen_sig = self.disc_sig = None     # shapes of the loaded generator batches / of the batch of the PENDING discriminator phase
+        self.flags = None
+        self.graphs = OrderedDict()   # (disc shapes, generator shapes, flags) -> _Captured, least recently used first
+        self.pool = None              # the captures' shared memory pool
         self.pending_lr = None        # learning rate of the D phase that has not run yet (None: nothing pending)
-        self.warmed = set()           # signatures whose shifted body has run eagerly once
+        self.warmed = OrderedDict()   # signatures whose shifted body has run eagerly once -> host ms of that run
+        self.stats = dict(captures=0, replays=0, eager_bodies=0, evictions=0)
         self.epoch = 0
         ops.step_state()              # device block + RNG-epoch pointer exist before any capture
 
@@ -70,30 +86,41 @@ class GraphedTrainStep:
         # capture then holds marker nodes and the stream-replay executor issues the collectives (ddp.native_comm, csrc/comm.cpp)
         return getattr(self.args, "cm_steps", 0) == 0 and (not ddp.active() or bool(ddp.native_comm()))
 
-    def _signature(self, batches):
+    def _signatures(self, batches):
         a = self.args
-        keys = [("unsup", a.ae_steps), ("sup", a.sp_steps)] + ([("disc", a.d_steps)] if a.use_discriminator else [])
-        sig = tuple((k, i, tuple(tuple(t.shape) for t in batches[k][i])) for k, n in keys for i in range(n))
-        return sig + (is_deterministic(), config.NSPLIT, self.model.training)
+        shp = lambda k, n: tuple((k, i, tuple(tuple(t.shape) for t in batches[k][i])) for i in range(n))
+        gen = shp("unsup", a.ae_steps) + shp("sup", a.sp_steps)
+        disc = shp("disc", a.d_steps) if a.use_discriminator else ()
+        return gen, disc, (is_deterministic(), config.NSPLIT, self.model.training)
 
-    def _load(self, batches, keys):
-        """Copies the batches into the static input buffers (device-to-device or host-to-device on the current stream)."""
+    def _copy_in(self, dsts, srcs):
+        for dst, src in zip(dsts, srcs):
+            for d, s in zip(dst, src):
+                if not (s.is_cuda and s.data_ptr() == d.data_ptr()):
+                    d.copy_(s, non_blocking=True)
+
+    def _load_gen(self, batches, gen_sig):
+        """Copies the generator batches into the static buffers of their shape (device-to-device or host-to-device on the current stream)."""
         dev = T._dev()
-        sig = self._signature(batches)
-        if self.static is None or self.sig != sig:
-            assert self.pending_lr is None
-            self.sig = sig
-            self.static = self.static_by_sig.get(sig)
-            if self.static is None:
-                self.static = self.static_by_sig[sig] = {}
-                a = self.args
-                for k, n in (("unsup", a.ae_steps), ("sup", a.sp_steps), ("disc", a.d_steps if a.use_discriminator else 0)):
-                    self.static[k] = [tuple(torch.empty(t.shape, dtype=t.dtype, device=dev) for t in batches[k][i]) for i in range(n)]
-        for k in keys:
-            for dst, src in zip(self.static[k], batches[k]):
-                for d, s in zip(dst, src):
-                    if not (s.is_cuda and s.data_ptr() == d.data_ptr()):
-                        d.copy_(s, non_blocking=True)
+        st = self.static_gen.get(gen_sig)
+        if st is None:
+            a = self.args
+            st = self.static_gen[gen_sig] = {k: [tuple(torch.empty(t.shape, dtype=t.dtype, device=dev) for t in batches[k][i]) for i in range(n)]
+                                             for k, n in (("unsup", a.ae_steps), ("sup", a.sp_steps))}
+        self.gen_sig = gen_sig
+        self.static["unsup"], self.static["sup"] = st["unsup"], st["sup"]
+        for k in ("unsup", "sup"):
+            self._copy_in(st[k], batches[k])
+
+    def _load_disc(self, batches, disc_sig):
+        dev = T._dev()
+        st = self.static_disc.get(disc_sig)
+        if st is None:
+            n = self.args.d_steps if self.args.use_discriminator else 0
+            st = self.static_disc[disc_sig] = [tuple(torch.empty(t.shape, dtype=t.dtype, device=dev) for t in batches["disc"][i]) for i in range(n)]
+        self.disc_sig = disc_sig
+        self.static["disc"] = st
+        self._copy_in(st, batches["disc"])
 
     def _gen_phase(self, losses):
         a, model = self.args, self.model
@@ -130,28 +157,38 @@ class GraphedTrainStep:
         if not model.training:
             model.train()
         model._store().sync_split()                       # parameters written through torch since the last step?
-        if self.sig is not None and self.pending_lr is not None and self._signature(batches) != self.sig:
-            self.flush(losses)                            # other input shapes: the pending D phase still belongs to the old buffers
+        gen_sig, disc_sig, flags = self._signatures(batches)
+        if self.pending_lr is not None and flags != self.flags:
+            self.flush(losses)                            # mode change (deterministic / eval): the pending D phase belongs to the old mode
+        self.flags = flags
         lr_now = float(opt.param_groups[0]["lr"])
         if a.use_discriminator and self.pending_lr is None:
             # first step (or first after flush()): generator phase only, eagerly; its D phase runs inside the next call
-            self._load(batches, ("unsup", "sup", "disc"))
+            self._load_gen(batches, gen_sig)
+            self._load_disc(batches, disc_sig)
             self._gen_phase(losses)
             join_streams()
         else:
-            self._load(batches, ("unsup", "sup"))          # "disc" still holds the previous step's batch: the body reads it first
-            sig = self.sig
+            self._load_gen(batches, gen_sig)               # static["disc"] still holds the previous step's batch: the body reads it first
+            sig = (self.disc_sig, gen_sig, flags)
             rec = self.graphs.get(sig)
             if rec is None and sig not in self.warmed:
-                # once eagerly with exactly the body's call sequence (lazy initialisations, allocator warm-up, stream creation)
+                # once eagerly with exactly the body's call sequence (lazy initialisations, allocator warm-up, stream creation); a pair of
+                # shapes that never comes back is never captured
+                t0 = time.perf_counter()
                 self._with_lrs(lambda: self._body(losses), lr_now)
-                self.warmed.add(sig)
+                self.warmed[sig] = (time.perf_counter() - t0) * 1e3
+                while len(self.warmed) > MAX_WARMED:
+                    self.warmed.popitem(last=False)
+                self.stats["eager_bodies"] += 1
             else:
                 if rec is None:
                     rec = self._capture(sig)
+                else:
+                    self.graphs.move_to_end(sig)           # most recently used
                 self._replay(rec, losses, lr_now)
             if a.use_discriminator:
-                self._load(batches, ("disc",))             # ordered behind the replay that read the previous one
+                self._load_disc(batches, disc_sig)         # ordered behind the replay that read the previous one
         if a.use_discriminator:
             self.pending_lr = lr_now
         if self.sched is not None:
@@ -181,14 +218,13 @@ class GraphedTrainStep:
         from .inference import _capture
         join_streams()
         torch.cuda.synchronize()
-        while len(self.graphs) >= MAX_GRAPHS:             # evict the oldest capture (nothing of it is in flight after the synchronize)
-            old = next(iter(self.graphs))
-            self._drop(old)
-        for old in [k for k in self.static_by_sig if k not in self.graphs and k != sig]:
-            if len(self.static_by_sig) <= MAX_GRAPHS:
-                break
-            del self.static_by_sig[old]
+        t0 = time.perf_counter()
+        while len(self.graphs) >= max(MAX_GRAPHS, 1):     # evict the least recently used capture (nothing of it is in flight after the synchronize)
+            self._drop(next(iter(self.graphs)))
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
         rec = _Captured()
+        rec.replays, rec.replay_host_ms = 0, 0.0
         cap_losses = defaultdict(list)
         self.opt.captured_ranges = []
         sync_flag, T.SYNC_LOSSES = T.SYNC_LOSSES, False
@@ -199,7 +235,7 @@ class GraphedTrainStep:
             rec.loss_keys = [k for k, _ in flat]
             rec.loss_vec = torch.stack([v.reshape(()) for _, v in flat]) if flat else None
         try:
-            rec.graph = _capture(fn, keep_graph=True)
+            rec.graph = _capture(fn, pool=self.pool, keep_graph=True)
         finally:
             T.SYNC_LOSSES = sync_flag
         rec.plan, rec.plan_info = 0, None
@@ -229,6 +265,9 @@ class GraphedTrainStep:
             rec.graph.instantiate()
         rec.ranges = list(self.opt.captured_ranges)
         self.graphs[sig] = rec
+        torch.cuda.synchronize()
+        rec.capture_ms = (time.perf_counter() - t0) * 1e3
+        self.stats["captures"] += 1
         return rec
 
     def _drop(self, sig):
@@ -237,11 +276,27 @@ class GraphedTrainStep:
             from ._lib import lib
             lib().unast_graph_plan_destroy(rec.plan)
             rec.plan = 0
-        if sig != self.sig:
-            self.static_by_sig.pop(sig, None)
-        self.warmed.discard(sig)
+        rec.graph = None
+        self.stats["evictions"] += 1
+        # static input buffers no capture reads any more (and that are not the loaded ones) go with it
+        used_d = {k[0] for k in self.graphs} | {self.disc_sig}
+        used_g = {k[1] for k in self.graphs} | {self.gen_sig}
+        for k in [k for k in self.static_disc if k not in used_d]:
+            del self.static_disc[k]
+        for k in [k for k in self.static_gen if k not in used_g]:
+            del self.static_gen[k]
+
+    def cache_report(self):
+        """Counters of the capture cache and, per cached capture, what it cost and what it saves: capture_ms (one-off), the host time of
+        the eager body it replaced (eager_host_ms, from the run that preceded the capture) and of its replays (replay_host_ms, mean)."""
+        per = []
+        for sig, rec in self.graphs.items():
+            per.append(dict(disc_shapes=sig[0], gen_shapes=sig[1], capture_ms=round(rec.capture_ms, 2), replays=rec.replays,
+                            replay_host_ms=round(rec.replay_host_ms / max(rec.replays, 1), 3), eager_host_ms=round(self.warmed.get(sig, float("nan")), 3)))
+        return dict(self.stats, cached=len(self.graphs), max_graphs=MAX_GRAPHS, shapes_gen=len(self.static_gen), shapes_disc=len(self.static_disc), per_capture=per)
 
     def _replay(self, rec, losses, lr_now):
+        t0 = time.perf_counter()
         hyper = {}
         dr = self.model._store().regions.get("disc")
         for rng in rec.ranges:
@@ -260,6 +315,9 @@ class GraphedTrainStep:
             snap = rec.loss_vec.clone()
             for i, k in enumerate(rec.loss_keys):
                 losses[k].append(snap[i])
+        rec.replays += 1
+        rec.replay_host_ms += (time.perf_counter() - t0) * 1e3
+        self.stats["replays"] += 1
 
     def flush(self, losses=None):
         """Runs the discriminator phase that is still pending (eagerly, joined): before evaluation, checkpoints, or reading

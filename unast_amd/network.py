@@ -89,6 +89,19 @@ class AutoEncoderNet(_Side):
         raise Exception("Please use a subclass for text or speech")
 
 
+def _lens_of_pad_mask(mask, T, device):
+    """Lengths behind a key-padding mask.  The kernels mask by length, so a bool mask [B,T] (True = padded; the reference's form,
+    src/network.py:411-413) must be a suffix mask, which is all the reference ever builds; int lengths (this package's masks[1])
+    pass through; None = nothing padded."""
+    if mask is None:
+        raise ValueError("pass the key-padding mask (bool [B,T]) or the lengths (int [B])")
+    if mask.dtype != torch.bool:
+        return lens_i32(mask, device)
+    if mask.shape[1] > 1 and bool((mask[:, 1:] < mask[:, :-1]).any()):
+        raise ValueError("key-padding masks must pad a suffix of each sequence (lengths are what the attention kernels take)")
+    return (T - mask.sum(dim=1)).to(device=device, dtype=torch.int32)
+
+
 def _out3d(tape, var2d, B, T):
     """Expose a [B*T, C] Var as a [B, T, C] output Var (a view; its gradient flows back as a view)."""
     o = Var(var2d.v.view(B, T, var2d.v.shape[1]))
@@ -179,8 +192,26 @@ class TextTransformer(AutoEncoderNet):
             return [o]
         return run_segment(run, ddp_hook("text_dec", cx.st), cx.st.dummy, enc_outputs)
 
+    @on_stream("text")
+    def decode(self, tgt, tgt_lens, tgt_pad_mask, enc_outputs, enc_mask):
+        """src/network.py:446-450: one uncached generation step -- the decoder over all of `tgt` (token ids [B,T], fed as they are),
+        logits [B,1,V] of its last position.  Forward only (no tape); generation proper runs on the K/V cache (infer_sequence)."""
+        B, T = tgt.shape
+        Tk = enc_outputs.shape[1]
+        lens_q = _lens_of_pad_mask(tgt_pad_mask, T, tgt.device)
+        lens_k = _lens_of_pad_mask(enc_mask, Tk, tgt.device)
+        cx = self._ctx()
+        with torch.no_grad():
+            out = F.text_decode(cx, None, self, tgt.contiguous(), lens_q, Var(enc_outputs.detach().contiguous().view(B * Tk, -1)), lens_k, Tk, shift=False)
+        V = self.postnet.fc1.weight.shape[0]
+        return out.v.view(B, T, -1)[:, -1:, :V]
+
+    @on_stream("text")
     def postprocess(self, out):
-        raise NotImplementedError("use decode_sequence(); the text post-net is fused into it")
+        """src/network.py:452-453: TextPostnet on decoder states [B,T,E] -> logits [B,T,V].  Forward only (the train step's post-net is
+        part of decode_sequence's segment)."""
+        with torch.no_grad():
+            return F.text_postnet(self._ctx(), self, out.detach())
 
     def forward(self, text, text_len, noise_in=False, teacher_ratio=1, ret_enc_hid=False):
         enc_outputs, masks = self.encode(text, text_len, noise_in)
@@ -269,8 +300,26 @@ class SpeechTransformer(AutoEncoderNet):
         pre, post, stop = run_segment(run, ddp_hook("speech_dec", cx.st), cx.st.dummy, enc_outputs)
         return pre, post, stop, tgt_lens
 
+    @on_stream("speech")
+    def decode(self, tgt, tgt_lens, tgt_pad_mask, enc_outputs, enc_mask):
+        """src/network.py:210-214: one uncached generation step -- the decoder over all of `tgt` ([B,T,M] frames, fed as they are),
+        (mel [B,1,M], stop logit [B,1,1]) of its last position.  Forward only; generation proper runs on the K/V cache."""
+        B, T, M = tgt.shape
+        Tk = enc_outputs.shape[1]
+        lens_q = _lens_of_pad_mask(tgt_pad_mask, T, tgt.device)
+        lens_k = _lens_of_pad_mask(enc_mask, Tk, tgt.device)
+        cx = self._ctx()
+        with torch.no_grad():
+            head, _ = F.speech_decode(cx, None, self, tgt.detach(), lens_q, Var(enc_outputs.detach().contiguous().view(B * Tk, -1)), lens_k, Tk,
+                                      shift=False, postnet=False)
+        h = head.v.view(B, T, -1)[:, -1:, :]
+        return h[..., :M], h[..., M:M + 1]
+
+    @on_stream("speech")
     def postprocess(self, out):
-        raise NotImplementedError("use decode_sequence(); the speech post-net is fused into it")
+        """src/network.py:216-217: SpeechPostnet on [B,T,M] frames (the residual term; callers add it to `out`).  Forward only."""
+        with torch.no_grad():
+            return F.speech_postnet_residual(self._ctx(), self, out.detach().contiguous(), residual=False)
 
     def forward(self, mel, mel_len, noise_in=False, teacher_ratio=1, ret_enc_hid=False):
         enc_outputs, masks = self.encode(mel, mel_len, noise_in)

@@ -650,6 +650,20 @@ def leaky_dropout(x, dy, out, slope, drop_p=0.0, seed=0, stream_id=0):
 
 
 # ---- optimizer ---------------------------------------------------------------------------------------------
+_MSE_WS = {}
+
+
+def masked_mse(gold, pred, mask):
+    """src/train.py:100-103 on flat fp32 tensors; returns a device scalar."""
+    dev = gold.device
+    ws = _MSE_WS.get(dev)
+    if ws is None:
+        ws = _MSE_WS[dev] = torch.zeros(3, dtype=torch.float64, device=dev)
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    check(lib().unast_masked_mse(_p(gold), _p(pred), _p(mask), gold.numel(), _p(ws), _p(out), _stream()), "unast_masked_mse")
+    return out
+
+
 def sumsq(g, out):
     check(lib().unast_sumsq(_p(g), g.numel(), _p(out), _stream()), "unast_sumsq")
 

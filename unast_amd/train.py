@@ -101,8 +101,13 @@ def _dummy(dev):
 
 
 def masked_mse(gold_mel, pred_mel, mel_mask):
-    """src/train.py:100-103 — kept for API completeness (the hot path uses the fused speech_loss)."""
-    raise NotImplementedError("masked_mse is fused into speech_loss (HIP kernel); call speech_loss")
+    """src/train.py:100-103: sum((gold - pred)^2 * mask) / sum(mask), a device scalar.  Forward only: the train step's two masked MSEs
+    and the stop loss come out of one fused kernel with their gradients (speech_loss below); this entry serves evaluation code that
+    calls it directly."""
+    gold, pred, mask = (t.detach().reshape(-1).to(torch.float32).contiguous() for t in (gold_mel, pred_mel, mel_mask))
+    if not (gold.numel() == pred.numel() == mask.numel()):
+        raise ValueError("masked_mse: gold, pred and mask must have the same number of elements")
+    return ops.masked_mse(gold, pred, mask)
 
 
 @on_stream("text")
@@ -501,12 +506,14 @@ def train(args, batch_getter=None, on_epoch_end=None, valid_dataloader=None):
     max_obj_steps = max(args.ae_steps, cm_steps, args.sp_steps, args.d_steps if args.use_discriminator else 0)
     accum_steps = args.ae_steps + cm_steps + args.sp_steps
     history = []
-    # args.use_hip_graphs (not a reference key; default off): the body of the hot loop as a captured graph (unast_amd.graphed),
-    # re-captured per input shape -- for fixed-shape batches (bucketed / padded loaders) on host-bound configurations.
+    # args.use_hip_graphs (not a reference key; default off): the body of the hot loop as a captured graph (unast_amd.graphed), one
+    # capture per pair of input shapes met twice, kept in an LRU -- for loaders whose batches repeat shapes (length-bucketed samplers)
+    # on host-bound configurations.  Batches must come as they are: padding them up to a bucket changes the result.
     stepper = None
     if getattr(args, "use_hip_graphs", False) and cm_steps == 0:
         from .graphed import GraphedTrainStep
         stepper = GraphedTrainStep(model, optimizer, scheduler, args)
+        model.__dict__["_graph_stepper"] = stepper         # (its cache_report() is how a caller sees captures / replays / evictions)
     for epoch in range(s_epoch, args.epochs):
         losses = defaultdict(list)
         for s in range(args.epoch_steps):
