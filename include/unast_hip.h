@@ -188,6 +188,9 @@ int unast_disc_gather(const float* t_hid, const float* s_hid, const int* t_len, 
 int unast_disc_scatter(const float* dout, const int64_t* perm, float* dt_hid, float* ds_hid, int B, int Tt, int Ts, int D,
                        hipStream_t stream);
 
+/* The sum of a sub-step's losses over accum_steps (src/train.py:376-378, 403-405, 455: loss = (a + b + c) / accum_steps) and its
+ * backward (grad / accum_steps) as one single-thread launch: out[0] = ((a[0] + b[0]) + c[0]) / div; b and c may be NULL. */
+int unast_scalar_combine(const float* a, const float* b, const float* c, float div, float* out, hipStream_t stream);
 /* masked_mse (src/train.py:100-103) on its own: out[0] = sum((gold - pred)^2 * mask) / sum(mask) over n elements.  ws3: three
  * doubles of workspace, zero on entry, left zero on exit.  (The train step's two masked MSEs come out of unast_speech_loss_*.) */
 int unast_masked_mse(const float* gold, const float* pred, const float* mask, int64_t n, double* ws3, float* out, hipStream_t stream);
@@ -254,11 +257,12 @@ int64_t unast_wgrad_group_ws_floats(int count, const unast_wgrad_item* items, in
  * captured HIP graph of the step replays with the current schedule values.
  * split_out (may be NULL; needs n % 4 == 0): the updated parameters once more in the GEMM's pre-split operand format --
  * per 4 consecutive elements one 16-byte chunk [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] of bf16, hi = RNE(x), lo = RNE(x - hi).
- * unast_split_f32 produces the same format from any fp32 buffer (model load, load_state_dict). */
+ * unast_split_f32 produces the same format from any fp32 buffer (model load, load_state_dict).
+ * zero_grad != 0: g is set to zero behind the update (optimizer.zero_grad() of src/train.py:363 in the same pass). */
 int unast_sumsq(const float* g, int64_t n, double* out, hipStream_t stream);
-int unast_adamw(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
+int unast_adamw(float* p, float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
                 float beta1, float beta2, float eps, float weight_decay, int step, float* split_out, int decoupled,
-                const float* dev_hyper, hipStream_t stream);
+                const float* dev_hyper, int zero_grad, hipStream_t stream);
 int unast_split_f32(const float* src, float* dst, int64_t n, hipStream_t stream);
 /* W^T of every 2-D weight of a parameter region once more in the pre-split operand format (dst[k][n], 4 consecutive n per 16-byte
  * chunk; destination rows padded to a multiple of 4 with zeros), refreshed after each optimizer step: the input-gradient GEMMs
@@ -284,7 +288,12 @@ int unast_transpose_split(const float* src_base, float* dst_base, const int* til
  *           -> torch TransformerEncoderLayer) the launch WRITES them next to C; with act == 0 and no bias (the input gradient through
  *           linear2) it READS them as the gate x = bit ? x * gate_scale : 0 -- relu' and the dropout mask of the hidden activation
  *           without re-reading it.
- * rows_per_wg: 128 (8 waves x 32 rows), 1128 (128 rows as 16 waves x 16 rows), 64 or 0 (library picks). */
+ * rows_per_wg: 128 (8 waves x 32 rows), 1128 (128 rows as 16 waves x 16 rows), 64 or 0 (library picks).
+ * K > 256 (needs K % 64 == 0, N % 256 == 0): the K-STREAMED form -- a workgroup owns 128 rows x 256 columns of C, K comes in groups
+ *           of 64 (weights by LDS-DMA from the same planes, activations one group ahead into registers).  Serves linear2 (K = 1024) with
+ *           its residual + LayerNorm epilogue and the input gradients of linear1 / the in-projections (K = 1024 / 768 / 512) with their
+ *           residual-gradient operand R.  Epilogues: bias, R, and with ln_gamma the LayerNorm one (dropout only there); no act / G /
+ *           out_split / gate_bits; rows_per_wg is ignored. */
 int unast_panel_gemm(const float* A, int lda, const void* w_planes, int64_t plane_bytes, float* C, int ldc, int M, int N, int K,
                      const float* bias, const float* R, int ldr, const float* G, int ldg, float gate_scale, int act,
                      float drop_p, unsigned int seed, unsigned int stream_id, int out_split,

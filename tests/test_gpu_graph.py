@@ -184,7 +184,7 @@ def test_graph_replay_with_alternating_input_shapes():
                     train.train_step(losses, model, opt, None, b, i, args, defer_d_phase=True)
             if graphed:
                 assert len(stepper.graphs) == 2 and len(stepper.static_gen) == 2 and len(stepper.static_disc) == 2
-                assert stepper.stats["captures"] == 2 and stepper.stats["replays"] == 6 and stepper.stats["evictions"] == 0, stepper.stats
+                assert stepper.stats["captures"] == 2 and stepper.stats["replays"] == 7 and stepper.stats["evictions"] == 0, stepper.stats
                 stepper.flush(losses)
             join_streams(); torch.cuda.synchronize()
         finally:

@@ -131,6 +131,54 @@ def test_keep_bits_gate_equals_the_activation_gate(drop):
         assert 0.2 < keep < 0.6
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 512), (1000, 256, 1024), (129, 512, 768), (4100, 256, 1024), (1, 256, 320)])
+def test_k_streamed_panel_equals_tile_gemm(M, N, K):
+    """K > 256 (the K-streamed form of unast_panel_gemm: 128 x 256 output tiles, K in groups of 64): plain, bias and residual epilogues and
+    the W^T planes of an input gradient, bit for bit against the tile GEMM."""
+    from unast_amd import ops
+    from unast_amd.planes import Planes
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, device=D)
+    W = torch.randn(N, K, device=D) * 0.05
+    b = torch.randn(N, device=D)
+    R = torch.randn(M, N, device=D)
+    pl = Planes([W])
+    for kw in (dict(), dict(bias=b), dict(bias=b, R=R), dict(R=R)):
+        y0 = torch.zeros(M, N, device=D)
+        ops.gemm(ops.OP_KC, ops.OP_KC, x, K, W, K, y0, N, M, N, K, bias=kw.get("bias"), R=kw.get("R"), ldr=N if "R" in kw else 0)
+        y1 = torch.full((M + 5, N), 3.0, device=D)
+        ops.panel_gemm(x, pl.ref(0), y1[:M], N, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1[:M]), (kw.keys(), float((y0 - y1[:M]).abs().max()))
+        assert bool((y1[M:] == 3.0).all())
+    # input gradient: dx[M, N] = dy[M, K] W2 with W2 stored [K, N] -> planes of W2^T
+    W2 = torch.randn(K, N, device=D) * 0.05
+    pt = Planes([W2], transposed=True)
+    d0 = torch.empty(M, N, device=D); d1 = torch.empty(M, N, device=D)
+    ops.gemm(ops.OP_KC, ops.OP_RC, x, K, W2, N, d0, N, M, N, K, R=R, ldr=N)
+    ops.panel_gemm(x, pt.ref(0), d1, N, R=R)
+    assert torch.equal(d0, d1), float((d0 - d1).abs().max())
+
+
+@pytest.mark.parametrize("M", [77, 640, 4100])
+def test_k_streamed_layernorm_epilogue(M):
+    from unast_amd import ops
+    from unast_amd.planes import Planes
+    torch.manual_seed(M)
+    K = 1024
+    x = torch.randn(M, K, device=D); W = torch.randn(256, K, device=D) * 0.03; b = torch.randn(256, device=D)
+    R = torch.randn(M, 256, device=D); gm = torch.rand(256, device=D) + 0.5; bt = torch.randn(256, device=D)
+    pl = Planes([W])
+    for drop in (0.0, 0.1):
+        z0 = torch.empty(M, 256, device=D); y0 = torch.empty_like(z0); m0 = torch.empty(M, device=D); r0 = torch.empty(M, device=D)
+        ops.gemm(ops.OP_KC, ops.OP_KC, x, K, W, K, z0, 256, M, 256, K, bias=b, drop_p=drop, seed=9, stream_id=2, R=R, ldr=256)
+        ops.layernorm_fwd(z0, gm, bt, y0, m0, r0, 1e-5)
+        z1 = torch.empty_like(z0); y1 = torch.empty_like(z0); m1 = torch.empty(M, device=D); r1 = torch.empty(M, device=D)
+        ops.panel_gemm(x, pl.ref(0), z1, 256, bias=b, R=R, drop_p=drop, seed=9, stream_id=2, ln=(gm, bt, y1, m1, r1, 1e-5))
+        assert torch.equal(z0, z1), float((z0 - z1).abs().max())
+        assert float((y0 - y1).abs().max()) < 5e-6 and float((m0 - m1).abs().max()) < 1e-6 and float(((r0 - r1) / r0).abs().max()) < 1e-6
+
+
 def test_train_step_with_and_without_the_panel_kernel_agree():
     """Two whole train steps (ae + sp + d sub-steps, clip + AdamW) with the row-panel kernel forced on for every eligible GEMM against the same
     steps on the tile GEMM."""

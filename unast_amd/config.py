@@ -76,6 +76,9 @@ PANEL_MIN_ROWS = int(os.environ.get("UNAST_PANEL_MIN_ROWS", "16384"))
 PANEL_ROWS = int(os.environ.get("UNAST_PANEL_ROWS", "1128"))
 # LayerNorm in the epilogue of the out-projection GEMMs (post-LN sub-layers): z, y, mean, rstd come out of one launch.
 PANEL_LN = os.environ.get("UNAST_PANEL_LN", "1") != "0"
+# K > 256 contractions into 256 columns (FFN linear2 with its LayerNorm, the input gradients of linear1 / the in-projections) on the
+# K-streamed form of the panel kernel
+PANEL_KSTREAM = os.environ.get("UNAST_PANEL_KSTREAM", "1") != "0"
 # linear1 writes one keep bit per hidden element (relu > 0 and not dropped); linear2's input-gradient GEMM gates with those bits
 # (scalar loads) instead of re-reading the 105 MB hidden activation.
 PANEL_GATE_BITS = os.environ.get("UNAST_PANEL_GATE_BITS", "1") != "0"

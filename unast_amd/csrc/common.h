@@ -61,9 +61,7 @@ __device__ __forceinline__ uint32_t rng_u32(uint32_t row_key, uint32_t col) { re
 // already well-mixed per-row key.  thresh = p * 2^16 (0 => keep everything).  All kernels (GEMM epilogue, LayerNorm
 // backward, attention forward/backward, element-wise) use these two helpers, so masks agree across passes.
 __device__ __forceinline__ uint32_t rng_pair(uint32_t row_key, uint32_t col) {
-    // 24-bit multiply (v_mul_u32_u24, full rate; a 32-bit v_mul_lo_u32 issues at a quarter of it -- 16 cycles -- and the attention kernels
-    // draw one of these per pair of scores): the low 24 bits of the already well-mixed per-row key, xor the column pair, times an odd constant
-    uint32_t h = __umul24((col >> 1) ^ row_key, 0x9E3779u);
+    uint32_t h = ((col >> 1) ^ row_key) * 0x9E3779B1u;
     return h ^ (h >> 15);
 }
 __device__ __forceinline__ bool rng_keep_lo(uint32_t pair_hash, uint32_t thresh) { return (pair_hash & 0xFFFFu) >= thresh; }

@@ -295,4 +295,19 @@ extern "C" int unast_masked_mse(const float* gold, const float* pred, const floa
     return unast_check_launch("unast_masked_mse");
 }
 
+__global__ __launch_bounds__(64) void scalar_combine_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, float div, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        float s = a[0];
+        if (b) s += b[0];
+        if (c) s += c[0];
+        out[0] = s / div;
+    }
+}
+
+extern "C" int unast_scalar_combine(const float* a, const float* b, const float* c, float div, float* out, hipStream_t stream) {
+    UNAST_REQUIRE(a && out && div != 0.f, "unast_scalar_combine: bad arguments");
+    hipLaunchKernelGGL(scalar_combine_kernel, dim3(1), dim3(64), 0, stream, a, b, c, div, out);
+    return unast_check_launch("unast_scalar_combine");
+}
+
 UNAST_DEFINE_RNG_EPOCH_SETTER(loss)

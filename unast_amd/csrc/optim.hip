@@ -26,10 +26,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 
 // n4 float4 groups (+ a scalar tail).  split_out (optional): the updated parameters again in the GEMM's pre-split operand
 // format -- per 4 consecutive elements one 16-B chunk [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] of bf16 (same byte offsets as fp32).
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     size_t n4, size_t n, const double* __restrict__ sumsq, float max_norm, float lr, float b1, float b2,
                                                     float eps, float wd, float bc1, float bc2_sqrt, float* __restrict__ split_out,
-                                                    int decoupled, const float* __restrict__ dev_hyper) {
+                                                    int decoupled, const float* __restrict__ dev_hyper, int zero_grad) {
     if (dev_hyper) { lr = dev_hyper[0]; bc1 = dev_hyper[1]; bc2_sqrt = dev_hyper[2]; }
     float coef = 1.f;
     if (max_norm > 0.f) {
@@ -53,12 +53,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         upd(P.x, G.x, M.x, V.x); upd(P.y, G.y, M.y, V.y); upd(P.z, G.z, M.z, V.z); upd(P.w, G.w, M.w, V.w);
         reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
         if (split_out) reinterpret_cast<uint4*>(split_out)[i] = split_chunk(P);
+        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);        // optimizer.zero_grad() of the same range, in the same pass
     }
     if (blockIdx.x == 0)
         for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
             float pp = p[i], mm = m[i], vv = v[i];
             upd(pp, g[i], mm, vv);
             p[i] = pp; m[i] = mm; v[i] = vv;
+            if (zero_grad) g[i] = 0.f;
         }
 }
 
@@ -78,9 +80,9 @@ extern "C" int unast_sumsq(const float* g, int64_t n, double* out, hipStream_t s
     return unast_check_launch("unast_sumsq");
 }
 
-extern "C" int unast_adamw(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
+extern "C" int unast_adamw(float* p, float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
                            float beta1, float beta2, float eps, float weight_decay, int step, float* split_out, int decoupled,
-                           const float* dev_hyper, hipStream_t stream) {
+                           const float* dev_hyper, int zero_grad, hipStream_t stream) {
     UNAST_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || dev_hyper), "unast_adamw: bad arguments");
     if (step < 1) step = 1;
     UNAST_REQUIRE(!(max_norm > 0.f) || sumsq, "unast_adamw: clipping needs the sum-of-squares scalar");
@@ -92,7 +94,7 @@ extern "C" int unast_adamw(float* p, const float* g, float* m, float* v, int64_t
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, (size_t)n / 4, (size_t)n, sumsq, max_norm, lr, beta1,
-                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), split_out, decoupled, dev_hyper);
+                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), split_out, decoupled, dev_hyper, zero_grad);
     return unast_check_launch("unast_adamw");
 }
 

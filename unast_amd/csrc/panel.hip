@@ -22,6 +22,7 @@
 #include "../../include/unast_hip.h"
 #include <type_traits>
 
+static unsigned long long* g_panel_stamps = nullptr;       // diagnostic builds (-DPANEL_STAMPS): device buffer for per-wave cycle sums
 #define PSUB 1024                  // bytes of one sub-tile: 16 columns x 32 k of bf16
 
 struct PanelParams {
@@ -569,6 +570,225 @@ extern "C" int unast_retile_weights(const float* src_base, void* dst_base, const
     return unast_check_launch("unast_retile_weights");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K-streamed panel (K > 256, N a multiple of 256): the OUTPUT is the stationary operand.  A workgroup of 16 waves owns 128 rows x 256
+// columns; wave (rg, ch) accumulates rows [32 rg, 32 rg + 32) x columns [64 ch, 64 ch + 64) -- two row tiles against four column
+// tiles, so every weight fragment read from LDS feeds 6 MFMAs (the A-stationary kernel above: 3; its 16-wave form is bound by the LDS
+// read port).  K streams in groups of 32 through two three-slot LDS rings filled by LDS-DMA two groups ahead: the weights of a group
+// (256 n x 32 k, both planes = 32 KB, from the same tiled planes) and the activations of a group (128 rows x 32 k of fp32 = 16 KB, whole
+// 128-byte row pieces, 8 rows per DMA instruction; every wave then reads its 32 rows as MFMA fragments and splits them).  One raw
+// s_barrier per group.  (A first version loaded the activation fragments straight into registers: correct, and 1.5x SLOWER than the tile
+// kernel -- every wave of a row group issued the same 16-rows-x-64-byte loads, 128 scattered load instructions per group and CU.)
+// Serves the contractions of the train step that reduce over more than 256 values into 256 columns: FFN linear2 (K = 1024) with its
+// residual + LayerNorm epilogue, and the input gradients of linear1 (K = 1024), of the self-attention in-projection (K = 768) and of
+// the cross-attention key/value projection (K = 512).
+// ---------------------------------------------------------------------------------------------------------------
+template <int LN>
+__global__ __launch_bounds__(1024, 4) void kpanel_kernel(const PanelParams p) {
+    constexpr int NW = 16, ROWS = 128, WSLOT = 32768, ASLOT = 16384;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * WSLOT + 3 * ASLOT + 1024 + 2048];       // W ring | A ring | bias (256 floats) | LayerNorm row sums (4 x 128 floats)
+    const int t = threadIdx.x, lane = t & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    __builtin_assume(wave >= 0 && wave < NW);
+    const int rg = wave >> 2, ch = wave & 3;
+    const int m_wg = blockIdx.x * ROWS, n_wg = blockIdx.y * 256;
+    const int m_wave = m_wg + 32 * rg;
+    const int KG = p.K >> 5;                              // groups = k-steps of the planes
+#ifdef PANEL_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // 0 wait vmcnt, 1 barrier, 2 DMA issue, 3 LDS reads -> activations there, 4 split -> weights there, 5 MFMA issue, 6 total, 7 epilogue
+    const unsigned long long t_begin = panel_stamp();
+#endif
+    const uint32_t rbase = p.drop_thresh ? rng_stream_base(p.seed, p.stream) : 0u;
+    unsigned char* const aring = smem + 3 * WSLOT;
+
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.W), 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0x7FFFFFF0, 0x00020000);
+    const int lane16 = lane * 16;
+    // A image of a group: row r (0..127) at r * 128, its 16-byte chunk c (4 k) at position c ^ key(r), key(r) = (r & 7) ^ ((r >> 3) & 1):
+    // the fragment reads below (16 rows x one chunk position per ds_read_b128 lane group) then cover all 64 banks exactly once.
+    // This wave copies rows 8 wave .. 8 wave + 7: lane -> row 8 wave + lane / 8, position lane % 8 (LDS-DMA writes lane-linear), so the
+    // swizzle is applied on the SOURCE side.  Rows >= M are clamped (computed, never stored).
+    const int ar = 8 * wave + (lane >> 3);
+    const uint32_t a_voff = ((uint32_t)min(m_wg + ar, p.M - 1) * (uint32_t)p.lda + 4u * (uint32_t)((lane & 7) ^ ((ar & 7) ^ ((ar >> 3) & 1)))) * 4u;
+    const uint32_t w_soff0 = (uint32_t)((n_wg >> 4) + wave) * (uint32_t)(KG * PSUB);           // this wave's column tile in a plane
+    auto issue_group = [&](int kg, int slot) {
+        // weights: sub-tile [plane q][column tile = wave] of k-step kg
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(smem + slot * WSLOT + (q * 16 + wave) * PSUB), 16, lane16,
+                                                     (int)((uint32_t)q * (uint32_t)p.plane_bytes + w_soff0 + (uint32_t)kg * PSUB), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(aring + slot * ASLOT + wave * 1024), 16, (int)a_voff, kg * 128, 0, 0);
+    };
+    float* const sbias = reinterpret_cast<float*>(smem + 3 * WSLOT + 3 * ASLOT);
+    float* const sred = sbias + 256;
+    if (t < 256) sbias[t] = p.bias ? p.bias[n_wg + t] : 0.f;
+    issue_group(0, 0);
+    if (KG > 1) issue_group(1, 1);
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // LDS byte addresses of this lane's fragment reads inside a slot
+    uint32_t a_rd[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r = 32 * rg + 16 * rt + l15, key = (r & 7) ^ ((r >> 3) & 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) a_rd[rt][h] = (uint32_t)(r * 128 + (((2 * g + h) ^ key) << 4));
+    }
+    const uint32_t aring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)aring;
+    const uint32_t wring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem + (uint32_t)(lane16 + (4 * ch) * PSUB);
+    int slot = 0;
+    for (int kg = 0; kg < KG; ++kg) {
+        // outstanding vector-memory operations of this wave: group kg (3) and, if it exists, group kg + 1 (3)
+        STAMP(ta);
+        if (kg + 1 < KG) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(tb);
+        __builtin_amdgcn_s_barrier();                     // every wave's share of group kg is in LDS, and nobody reads group kg - 1 (the slot refilled next) any more
+        STAMP(tc);
+        if (kg + 2 < KG) issue_group(kg + 2, slot == 0 ? 2 : slot - 1);
+        STAMP(td);
+        // (inline asm reads: before an ordinary LDS read hipcc waits vmcnt(0) for the LDS-DMA it believes may alias it)
+        f32x4 raw[2][2];
+        {
+            const uint32_t ab = aring_lds + (uint32_t)slot * ASLOT;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
+                         : "=&v"(raw[0][0]), "=&v"(raw[0][1]), "=&v"(raw[1][0]), "=&v"(raw[1][1])
+                         : "v"(ab + a_rd[0][0]), "v"(ab + a_rd[0][1]), "v"(ab + a_rd[1][0]), "v"(ab + a_rd[1][1]) : "memory");
+        }
+        const uint32_t wb = wring_lds + (uint32_t)slot * WSLOT;
+        bf16x8_t bh[4], bl[4];
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16384\n\tds_read_b128 %2, %8 offset:1024\n\tds_read_b128 %3, %8 offset:17408\n\t"
+                     "ds_read_b128 %4, %8 offset:2048\n\tds_read_b128 %5, %8 offset:18432\n\tds_read_b128 %6, %8 offset:3072\n\tds_read_b128 %7, %8 offset:19456"
+                     : "=&v"(bh[0]), "=&v"(bl[0]), "=&v"(bh[1]), "=&v"(bl[1]), "=&v"(bh[2]), "=&v"(bl[2]), "=&v"(bh[3]), "=&v"(bl[3]) : "v"(wb) : "memory");
+        // (the waits carry the registers as operands: to the compiler an asm's outputs are ready when the statement ends, and it had moved the
+        // conversions and the first MFMAs ahead of a bare s_waitcnt)
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]) :: "memory");
+        STAMP(te);
+        bf16x8_t ah[2], al[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            u32x2 h0, l0, h1, l1;
+            split4<3>(make_float4(raw[rt][0][0], raw[rt][0][1], raw[rt][0][2], raw[rt][0][3]), h0, l0);
+            split4<3>(make_float4(raw[rt][1][0], raw[rt][1][1], raw[rt][1][2], raw[rt][1][3]), h1, l1);
+            ah[rt] = __builtin_bit_cast(bf16x8_t, (u32x4){h0[0], h0[1], h1[0], h1[1]});
+            al[rt] = __builtin_bit_cast(bf16x8_t, (u32x4){l0[0], l0[1], l1[0], l1[1]});
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]), "+v"(bh[2]), "+v"(bl[2]), "+v"(bh[3]), "+v"(bl[3]) :: "memory");
+        STAMP(tf);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                acc[rt][ct] = mfma16(bl[ct], ah[rt], acc[rt][ct]);
+                acc[rt][ct] = mfma16(bh[ct], al[rt], acc[rt][ct]);
+                acc[rt][ct] = mfma16(bh[ct], ah[rt], acc[rt][ct]);
+            }
+#ifdef PANEL_STAMPS
+        asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][3]));        // the stamp below is taken when the last MFMA has ISSUED, not retired
+#endif
+        STAMP(tg);
+        STAMP_ADD(0, ta, tb); STAMP_ADD(1, tb, tc); STAMP_ADD(2, tc, td); STAMP_ADD(3, td, te); STAMP_ADD(4, te, tf); STAMP_ADD(5, tf, tg);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+#ifdef PANEL_STAMPS
+    const unsigned long long t_loop = panel_stamp();
+#endif
+    __syncthreads();                                      // (bias words visible whatever KG; the ring is idle: every DMA has been waited for)
+    // lane holds C[m = m_wave + 16 rt + l15][n = n_wg + 64 ch + 16 ct + 4 g .. + 3]
+    if constexpr (!LN) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int m = m_wave + 16 * rt + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int nl = 64 * ch + 16 * ct + 4 * g, n = n_wg + nl;
+                const float4 b4 = *reinterpret_cast<const float4*>(sbias + nl);
+                float4 o = make_float4(acc[rt][ct][0] + b4.x, acc[rt][ct][1] + b4.y, acc[rt][ct][2] + b4.z, acc[rt][ct][3] + b4.w);
+                if (p.R) { const float4 r4 = *reinterpret_cast<const float4*>(p.R + (size_t)m * p.ldr + n); o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w; }
+                *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + n) = o;
+            }
+        }
+    } else {
+        // z = R + dropout(acc + bias); y = LayerNorm(z) over the 256 columns of the row: this lane holds 16 of them, the three other lane
+        // groups g of the wave 48 more, the waves ch' != ch of the row group the other 192.
+        float mu[2], s1[2], s2[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int m = min(m_wave + 16 * rt + l15, p.M - 1);
+            uint32_t rkey = 0;
+            if (p.drop_thresh) rkey = pcg_hash((uint32_t)m + rbase);
+            s1[rt] = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int n = 64 * ch + 16 * ct + 4 * g;
+                const float4 b4 = *reinterpret_cast<const float4*>(sbias + n);
+                const float4 r4 = p.R ? *reinterpret_cast<const float4*>(p.R + (size_t)m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[rt][ct][r] + bb[r];
+                    if (p.drop_thresh) x = rng_keep(rkey, (uint32_t)(n + r), p.drop_thresh) ? x * p.drop_scale : 0.f;
+                    x += rr[r];
+                    acc[rt][ct][r] = x;
+                    s1[rt] += x;
+                }
+            }
+            s1[rt] += __shfl_xor(s1[rt], 16, 64);
+            s1[rt] += __shfl_xor(s1[rt], 32, 64);
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) sred[ch * 128 + 32 * rg + 16 * rt + l15] = s1[rt];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int r0 = 32 * rg + 16 * rt + l15;
+            mu[rt] = ((sred[r0] + sred[128 + r0]) + (sred[256 + r0] + sred[384 + r0])) * (1.f / 256.f);
+            s2[rt] = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = acc[rt][ct][r] - mu[rt]; s2[rt] += d * d; }
+            s2[rt] += __shfl_xor(s2[rt], 16, 64);
+            s2[rt] += __shfl_xor(s2[rt], 32, 64);
+        }
+        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) sred[ch * 128 + 32 * rg + 16 * rt + l15] = s2[rt];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int r0 = 32 * rg + 16 * rt + l15, m = m_wg + r0;
+            const float rs = rsqrtf(((sred[r0] + sred[128 + r0]) + (sred[256 + r0] + sred[384 + r0])) * (1.f / 256.f) + p.eps);
+            if (m >= p.M) continue;
+            if (g == 0 && ch == 0) { p.mean[m] = mu[rt]; p.rstd[m] = rs; }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int n = 64 * ch + 16 * ct + 4 * g;
+                const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + n), b4 = *reinterpret_cast<const float4*>(p.beta + n);
+                const f32x4 z = acc[rt][ct];
+                *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + n) = make_float4(z[0], z[1], z[2], z[3]);
+                *reinterpret_cast<float4*>(p.Y + (size_t)m * p.ldy + n) =
+                    make_float4((z[0] - mu[rt]) * rs * g4.x + b4.x, (z[1] - mu[rt]) * rs * g4.y + b4.y, (z[2] - mu[rt]) * rs * g4.z + b4.z, (z[3] - mu[rt]) * rs * g4.w + b4.w);
+            }
+        }
+    }
+#ifdef PANEL_STAMPS
+    if (p.stamps && lane == 0) {
+        const unsigned long long t_end = panel_stamp();
+        stamp_sum[6] = t_end - t_begin; stamp_sum[7] = t_end - t_loop;
+        for (int k = 0; k < 8; ++k) p.stamps[((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 16 + wave) * 8 + k] = stamp_sum[k];
+    }
+#endif
+}
+
 template <int KSTEPS>
 static void panel_launch(const PanelParams& p, int rows, int ln, hipStream_t s) {
     // rows 64: 8 waves x 16 rows; 128: 8 waves x 32 rows (256 VGPRs, 2 waves / SIMD); 1128: 128 rows as 16 waves x 16 rows (128 VGPRs, 4 waves / SIMD)
@@ -586,7 +806,6 @@ static void panel_launch(const PanelParams& p, int rows, int ln, hipStream_t s) 
     }
 }
 
-static unsigned long long* g_panel_stamps = nullptr;
 // Diagnostic builds (-DPANEL_STAMPS, tools/panel_stamps.py): device buffer of 8 x 8 x workgroups uint64 that receives per-wave cycle sums.
 extern "C" int unast_panel_debug_stamps(void* dev_buf) { g_panel_stamps = (unsigned long long*)dev_buf; return 0; }
 
@@ -596,6 +815,25 @@ extern "C" int unast_panel_gemm(const float* A, int lda, const void* w_planes, i
                                 const float* ln_gamma, const float* ln_beta, float* Y, int ldy, float* mean, float* rstd, float eps,
                                 void* gate_bits, int rows_per_wg, hipStream_t stream) {
     UNAST_REQUIRE(A && w_planes && C && M > 0 && N > 0 && K >= 4, "unast_panel_gemm: bad arguments");
+    if (K > 256) {
+        // K-streamed form: output-stationary 128 x 256 tiles
+        UNAST_REQUIRE((K & 63) == 0 && (N & 255) == 0 && (lda & 3) == 0 && (ldc & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)C) | ((uintptr_t)w_planes)) & 15) == 0,
+                      "unast_panel_gemm: K > 256 needs K %% 64 == 0, N %% 256 == 0, 16-byte row strides and aligned operands (N=%d K=%d)", N, K);
+        UNAST_REQUIRE(!G && !act && !out_split && !gate_bits, "unast_panel_gemm: K > 256 serves the plain, residual and LayerNorm epilogues only");
+        UNAST_REQUIRE(!R || ((ldr & 3) == 0 && (((uintptr_t)R) & 15) == 0), "unast_panel_gemm: residual operand must be 16-byte addressable");
+        const int lnk = ln_gamma != nullptr;
+        UNAST_REQUIRE(lnk || drop_p <= 0.f, "unast_panel_gemm: K > 256: dropout only inside the LayerNorm epilogue");
+        UNAST_REQUIRE(!lnk || (N == 256 && ln_beta && Y && mean && rstd && (ldy & 3) == 0), "unast_panel_gemm: the LayerNorm epilogue needs N = 256, Y / mean / rstd and 16-byte row strides");
+        PanelParams q = {};
+        q.stamps = g_panel_stamps;
+        q.A = A; q.lda = lda; q.W = (const unsigned char*)w_planes; q.plane_bytes = (size_t)plane_bytes; q.C = C; q.ldc = ldc; q.M = M; q.N = N; q.K = K; q.ncg = N / 64;
+        q.bias = bias; q.R = R; q.ldr = ldr; q.drop_thresh = drop_threshold(drop_p); q.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; q.seed = seed; q.stream = stream_id;
+        q.gamma = ln_gamma; q.beta = ln_beta; q.Y = Y; q.ldy = ldy; q.mean = mean; q.rstd = rstd; q.eps = eps;
+        dim3 grid((M + 127) / 128, N / 256);
+        if (lnk) hipLaunchKernelGGL((kpanel_kernel<1>), grid, dim3(1024), 0, stream, q);
+        else     hipLaunchKernelGGL((kpanel_kernel<0>), grid, dim3(1024), 0, stream, q);
+        return unast_check_launch("unast_panel_gemm");
+    }
     UNAST_REQUIRE((K & 3) == 0 && K <= 256 && (lda & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)C) | ((uintptr_t)w_planes)) & 15) == 0,
                   "unast_panel_gemm: needs K %% 4 == 0, K <= 256, lda %% 4 == 0 and 16-byte aligned operands (K=%d lda=%d)", K, lda);
     UNAST_REQUIRE(rows_per_wg == 0 || rows_per_wg == 64 || rows_per_wg == 128 || rows_per_wg == 1128, "unast_panel_gemm: rows_per_wg is 64, 128, 1128 (128 rows, 16 waves) or 0 (auto)");

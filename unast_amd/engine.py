@@ -387,6 +387,7 @@ class FlatStore:
         ops.register_weight_span(self.flat.data_ptr(), self.total * 4, self.flat_split.data_ptr(), self.dgrad_T, self.planes_of)
         self.dummy = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)   # forces autograd to call our backward
         self.touched = set()           # regions that received gradients since the last zero_grad
+        self.zeroed_by_step = set()    # regions whose gradients the optimizer's update pass has already zeroed (FusedAdamW.step(zero_grads=True))
         self.grads_exposed = False
 
     def __del__(self):
@@ -464,7 +465,7 @@ class FlatStore:
 
     # tiled bf16 planes (B operand of the row-panel GEMM, csrc/panel.hip) ------------------------------------------------
     def _build_planes(self):
-        """Every 2-D weight W [rows, K] with K <= 256 gets tiled hi / lo planes of itself (forward operand) and, when rows <= 256,
+        """Every 2-D weight W [rows, K] that planes.eligible accepts gets tiled hi / lo planes of itself (forward operand) and
         of W^T (the operand of its input-gradient GEMM dX = dY W); combined operands (the [81, 256] head, the LSTM's [2 * 4H, Din]
         input projections) and the q rows of the cross-attention in-projections likewise.  `refresh_planes` re-tiles a region with
         one launch (unast_retile_weights) after every optimizer step and whenever sync_split() sees parameters written through torch."""
@@ -476,8 +477,9 @@ class FlatStore:
         for n, p in self.params.items():
             if p.dim() == 2 and not n.endswith(".conv.weight"):
                 cands.append((self.offsets[n], p.shape[1], p.shape[0], p.shape[1], _region_of(n)))
-                if n.endswith("multihead_attn.in_proj_weight") and p.shape[0] == 3 * p.shape[1]:      # q rows: their own W^T
+                if n.endswith("multihead_attn.in_proj_weight") and p.shape[0] == 3 * p.shape[1]:      # q rows and k/v rows: their own W^T
                     cands.append((self.offsets[n], p.shape[1], p.shape[1], p.shape[1], _region_of(n)))
+                    cands.append((self.offsets[n] + p.shape[1] * p.shape[1], p.shape[1], 2 * p.shape[1], p.shape[1], _region_of(n)))
         P = self.params
         if "speech_m.postnet.linear_project.weight" in P:
             a, b = P["speech_m.postnet.linear_project.weight"], P["speech_m.postnet.stop_linear.weight"]
@@ -587,9 +589,12 @@ class FlatStore:
     def zero_grad(self):
         ops.reset_wgrad_choices()
         for r in self.touched:
+            if r in self.zeroed_by_step:
+                continue
             a, b = self.regions[r]
             self.grad[a:b].zero_()
         self.touched = set()
+        self.zeroed_by_step = set()
         for p in self.params.values():
             p.grad = None
 

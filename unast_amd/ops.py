@@ -116,8 +116,10 @@ def _splitk_for(M, N, K):
     return max(1, min(want, ksteps // SPLITK_MIN_KSTEPS))
 
 
-def _panel_ok(M, K, *tensors):
-    if not (config.PANEL_GEMM and config.NSPLIT == 3 and M >= config.PANEL_MIN_ROWS and 4 <= K <= 256 and K % 4 == 0):
+def _panel_ok(M, K, *tensors, N=None):
+    if not (config.PANEL_GEMM and config.NSPLIT == 3 and M >= config.PANEL_MIN_ROWS and K >= 4 and K % 4 == 0):
+        return False
+    if K > 256 and not (config.PANEL_KSTREAM and K % 64 == 0 and N is not None and N % 256 == 0):      # the K-streamed form: 256-column output tiles
         return False
     for t in tensors:
         if t is not None and (t.stride(-1) != 1 or t.data_ptr() % 16 or t.stride(0) % 4):
@@ -132,7 +134,9 @@ def linear_fwd(x2d, W, bias, out, act=0, drop_p=0.0, seed=0, stream_id=0, R=None
     M, K = x2d.shape
     N = W.shape[0]
     fuse_ln = ln is not None and config.PANEL_LN and N == 256 and not out_split and act == 0
-    if _panel_ok(M, K, x2d, out, R) and W.stride(1) == 1 and (R is None or fuse_ln):       # (a residual operand is served by the LayerNorm epilogue only)
+    deep = K > 256                                  # K-streamed form: plain / residual / LayerNorm epilogues (dropout inside the LayerNorm one only)
+    if _panel_ok(M, K, x2d, out, R, N=N) and W.stride(1) == 1 and (R is None or fuse_ln or deep) and \
+            not (deep and (act or out_split or gate_bits is not None or (drop_p > 0 and not fuse_ln))):       # (K <= 256: a residual operand is served by the LayerNorm epilogue only)
         wp = _weight_planes(W)
         if wp is not None:
             panel_gemm(x2d, wp, out, N, bias=bias, R=R, act=act, drop_p=drop_p, seed=seed, stream_id=stream_id, out_split=out_split,
@@ -156,7 +160,7 @@ def gate_bits_bytes(M, N):
 
 def panel_serves(M, K, W, transposed=False):
     """True when linear_fwd (transposed=False) / linear_dgrad (True) of this shape and stored weight run on the row-panel kernel."""
-    return _panel_ok(M, K) and W.stride(1) == 1 and _weight_planes(W, transposed) is not None
+    return _panel_ok(M, K, N=(W.shape[1] if transposed else W.shape[0])) and W.stride(1) == 1 and _weight_planes(W, transposed) is not None
 
 
 def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0, out_split=False, gate_bits=None):
@@ -164,10 +168,12 @@ def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0, out_split=
     activation that G would be (panel kernel only): the gate is read from them with scalar loads instead of from G."""
     M, N = dy2d.shape
     K = W.shape[1]
-    if N % 4 == 0 and R is None and G is None and _panel_ok(M, N, dy2d, dx) and beta == 0 and W.stride(1) == 1:
+    deep = N > 256                                  # K-streamed form (contraction over N): residual operand allowed, no gate, no split output
+    if N % 4 == 0 and G is None and _panel_ok(M, N, dy2d, dx, R, N=K) and beta == 0 and W.stride(1) == 1 and \
+            (R is None if not deep else (gate_bits is None and not out_split)):
         wp = _weight_planes(W, transposed=True)                # dX[M,K] = dY[M,N] (W^T)[K,N]^T: W^T planes, contraction over N
         if wp is not None:
-            panel_gemm(dy2d, wp, dx, K, gate_scale=gate_scale, out_split=out_split, rows_per_wg=config.PANEL_ROWS, gate_bits=gate_bits)
+            panel_gemm(dy2d, wp, dx, K, R=R, gate_scale=gate_scale, out_split=out_split, rows_per_wg=config.PANEL_ROWS, gate_bits=gate_bits)
             return dx
     if gate_bits is not None:
         raise RuntimeError("linear_dgrad: gate_bits needs the row-panel kernel (check ops.panel_serves first)")
@@ -668,10 +674,19 @@ def sumsq(g, out):
     check(lib().unast_sumsq(_p(g), g.numel(), _p(out), _stream()), "unast_sumsq")
 
 
-def adamw(p, g, m, v, sumsq_scalar, max_norm, lr, beta1, beta2, eps, wd, step, split_out=None, decoupled=True, dev_hyper=None):
+def scalar_combine(xs, div, out):
+    """out = (xs[0] + xs[1] + xs[2]) / div over 1 to 3 device scalars."""
+    a = xs[0]
+    b = xs[1] if len(xs) > 1 else None
+    c = xs[2] if len(xs) > 2 else None
+    check(lib().unast_scalar_combine(_p(a), _p(b), _p(c), float(div), _p(out), _stream()), "unast_scalar_combine")
+    return out
+
+
+def adamw(p, g, m, v, sumsq_scalar, max_norm, lr, beta1, beta2, eps, wd, step, split_out=None, decoupled=True, dev_hyper=None, zero_grad=False):
     """dev_hyper: float32 [3] device tensor {lr, 1 - beta1^t, sqrt(1 - beta2^t)} read by the kernel instead of lr / step."""
     check(lib().unast_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq_scalar), max_norm, lr, beta1, beta2, eps, wd, step,
-                            _p(split_out), int(bool(decoupled)), _p(dev_hyper), _stream()), "unast_adamw")
+                            _p(split_out), int(bool(decoupled)), _p(dev_hyper), int(bool(zero_grad)), _stream()), "unast_adamw")
 
 
 def adam_hyper(lr, beta1, beta2, step):

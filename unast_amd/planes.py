@@ -1,6 +1,7 @@
 """Tiled bf16 planes of weight matrices: the B-operand format of the row-panel GEMM (csrc/panel.hip, unast_panel_gemm).
 
-A destination matrix Wd[n][k] (n < N output columns of the GEMM, k < K <= 256 contraction index) is stored as a hi plane and a
+A destination matrix Wd[n][k] (n < N output columns of the GEMM, k < K contraction index; K <= 256 for the activation-stationary form
+of the kernel, a multiple of 64 beyond that for its K-streamed form) is stored as a hi plane and a
 lo plane of bf16 (hi = RNE(x), lo = RNE(x - hi)), each cut into 1-KB sub-tiles of 16 n x 32 k, padded with zeros to multiples of
 64 n and 32 k.  `plan` lays several matrices out in one buffer and returns the block descriptors unast_retile_weights consumes
 (include/unast_hip.h); no arithmetic happens here.
@@ -23,6 +24,8 @@ def geometry(N, K):
 
 
 def eligible(N, K):
+    if K > MAX_K:                              # the K-streamed form of the kernel: 64-deep groups of K into 256-column output tiles
+        return K % 64 == 0 and K <= 8192 and N % 256 == 0
     return 4 <= K <= MAX_K and K % 4 == 0 and (K + 31) // 32 in KSTEPS_BUILT and N >= 1
 
 

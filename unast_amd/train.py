@@ -47,7 +47,9 @@ def process_batch(batch):
     text, mel, text_len, mel_len = batch
     dev = _dev()
     text, mel = text.to(dev, non_blocking=True), mel.to(dev, non_blocking=True)
-    text_len, mel_len = text_len.to(dev, non_blocking=True), mel_len.to(dev, non_blocking=True)
+    # lengths as int32 on the device, once per batch: every kernel takes them in that form (the reference keeps int64; nothing on this
+    # path indexes with them), and 19 call sites per step would otherwise each convert them again
+    text_len, mel_len = text_len.to(dev, torch.int32, non_blocking=True), mel_len.to(dev, torch.int32, non_blocking=True)
     gold_mel, gold_char = mel.detach(), text.detach()
     gold_stop = _GoldStop(mel_len, mel.shape[1])
     return (text, mel, text_len, mel_len), (gold_char, gold_mel, gold_stop)
@@ -63,7 +65,7 @@ class _GoldStop:
         return self
 
     def dense(self):
-        return torch.nn.functional.one_hot(self.mel_len - 1, self.T).float()
+        return torch.nn.functional.one_hot(self.mel_len.long() - 1, self.T).float()
 
 
 #####----- LOSS FUNCTIONS -----#####
@@ -87,6 +89,42 @@ def _scalar_segment(fwd, bwd, *inputs):
             tape.record(back)
         return [o]
     return run_segment(run, None, dummy, *inputs)
+
+
+class _LossSum(torch.autograd.Function):
+    """loss = (a + b + c) / accum_steps of a sub-step (src/train.py:376-378) as one launch forward and one backward (torch: two adds, a
+    division, and in the backward a fill, a division and the fan-out)."""
+
+    @staticmethod
+    def forward(ctx, div, *xs):
+        ctx.div = div
+        ctx.n = len(xs)
+        out = torch.empty((), dtype=torch.float32, device=xs[0].device)
+        return ops.scalar_combine([x.detach() for x in xs], div, out)
+
+    @staticmethod
+    def backward(ctx, g):
+        gg = torch.empty((), dtype=torch.float32, device=g.device)
+        ops.scalar_combine([g.contiguous()], ctx.div, gg)
+        return (None,) + (gg,) * ctx.n
+
+
+_ONES = {}
+
+
+def _sum_and_backward(parts, accum_steps):
+    """loss = sum(parts) / accum_steps; loss.backward() seeded from a resident 1.0 (no fill launch).  Device scalars in, device scalar out."""
+    if not all(p.dim() == 0 and p.dtype == torch.float32 and p.is_cuda for p in parts) or len(parts) > 3:
+        loss = sum(parts[1:], parts[0]) / accum_steps
+        loss.backward()
+        return loss
+    loss = _LossSum.apply(float(accum_steps), *parts)
+    dev = loss.device
+    one = _ONES.get(dev)
+    if one is None:
+        one = _ONES[dev] = torch.ones((), dtype=torch.float32, device=dev)
+    torch.autograd.backward([loss], [one])
+    return loss
 
 
 _DUMMIES = {}
@@ -331,11 +369,11 @@ def optimizer_step(model, optimizer, args, defer=False):
         if ds is not None:                     # D phase: clip + AdamW + zero_grad of the discriminator range on its own stream
             with torch.cuda.stream(ds):
                 join_wgrad_streams()           # its weight gradients were accumulated on the companion stream
-                optimizer.step(max_norm=float(args.grad_clip))
+                optimizer.step(max_norm=float(args.grad_clip), zero_grads=True)     # (the AdamW pass leaves the range's gradients zero)
                 optimizer.zero_grad(set_to_none=True)
             return
         join_streams()                         # gradients were written by up to three streams
-        optimizer.step(max_norm=float(args.grad_clip))
+        optimizer.step(max_norm=float(args.grad_clip), zero_grads=True)
         optimizer.zero_grad(set_to_none=True)
         return
     join_streams()
@@ -353,14 +391,12 @@ def train_sp_step(losses, model, batch, step, accum_steps, args):
     with side_streams():                       # text side / speech side / discriminator on three HIP streams
         if args.use_discriminator:
             asr_loss, tts_loss, d_sp_loss = supervised_step(model, batch, args, args.use_discriminator)
-            join_streams()     # the loss scalars come from three streams; the sums below are torch ops
-            loss = tts_loss + asr_loss + d_sp_loss
+            join_streams()     # the loss scalars come from three streams
+            loss = _sum_and_backward([tts_loss, asr_loss, d_sp_loss], accum_steps)
         else:
             asr_loss, tts_loss = supervised_step(model, batch, args)
             join_streams()
-            loss = tts_loss + asr_loss
-        loss = loss / accum_steps
-        loss.backward()
+            loss = _sum_and_backward([tts_loss, asr_loss], accum_steps)
     losses['asr_'].append(_log(asr_loss))
     losses['tts_'].append(_log(tts_loss))
     if args.use_discriminator:
@@ -375,13 +411,11 @@ def train_ae_step(losses, model, batch, step, accum_steps, args):
         if args.use_discriminator:
             t_ae_loss, s_ae_loss, d_ae_loss = autoencoder_step(model, batch, args, args.use_discriminator)
             join_streams()
-            loss = t_ae_loss + s_ae_loss + d_ae_loss
+            loss = _sum_and_backward([t_ae_loss, s_ae_loss, d_ae_loss], accum_steps)
         else:
             t_ae_loss, s_ae_loss = autoencoder_step(model, batch, args)
             join_streams()
-            loss = t_ae_loss + s_ae_loss
-        loss = loss / accum_steps
-        loss.backward()
+            loss = _sum_and_backward([t_ae_loss, s_ae_loss], accum_steps)
     losses['t_ae'].append(_log(t_ae_loss))
     losses['s_ae'].append(_log(s_ae_loss))
     if args.use_discriminator:
@@ -416,15 +450,13 @@ def train_discriminator_step(losses, model, batch, step, accum_steps, args, log_
         ds = stream_of("disc") if (ctx.active and defer) else None
         if ds is None:
             join_streams()
-            loss = d_loss / accum_steps
-            loss.backward()
+            loss = _sum_and_backward([d_loss], accum_steps)
         else:
             # The whole D phase (forward, backward, and the optimizer step that follows) stays on the discriminator's stream:
             # with that stream ambient during backward the caller's stream never waits for it, so the next step's generator
             # forward (which does not read D's weights until its own D call, issued on this same stream) overlaps it.
             with torch.cuda.stream(ds):
-                loss = d_loss / accum_steps
-                loss.backward()
+                loss = _sum_and_backward([d_loss], accum_steps)
             ctx.leave_open = True
     losses['d'].append(_log(d_loss))
     return loss
@@ -689,7 +721,9 @@ class FusedAdamW(torch.optim.Optimizer):
             self._ss = torch.zeros(1, dtype=torch.float64, device=st.flat.device)
 
     @torch.no_grad()
-    def step(self, max_norm=0.0, closure=None):
+    def step(self, max_norm=0.0, closure=None, zero_grads=False):
+        """zero_grads: the update pass also zeroes the gradients of the ranges it steps (the zero_grad() that follows it in
+        optimizer_step, src/train.py:358-363, then has nothing left to fill)."""
         st = self.model._store()
         self._buffers(st)
         ranges = st.active_ranges()
@@ -714,14 +748,16 @@ class FusedAdamW(torch.optim.Optimizer):
                 slot = self._slots.setdefault((a, b), len(self._slots))
                 ops.adamw(st.flat[a:b], st.grad[a:b], self._m[a:b], self._v[a:b], self._ss, float(max_norm), 0.0,
                           g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], 0, split_out=st.flat_split[a:b],
-                          decoupled=self.decoupled, dev_hyper=ops.hyper_slot(slot))
+                          decoupled=self.decoupled, dev_hyper=ops.hyper_slot(slot), zero_grad=zero_grads)
                 self.captured_ranges.append((a, b))
                 continue
             self._steps[(a, b)] += 1
             ops.adamw(st.flat[a:b], st.grad[a:b], self._m[a:b], self._v[a:b], self._ss, float(max_norm), float(g["lr"]),
                       g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps[(a, b)], split_out=st.flat_split[a:b],
-                      decoupled=self.decoupled)
+                      decoupled=self.decoupled, zero_grad=zero_grads)
         upd = [r for r, ab in st.regions.items() if ab in ranges]
+        if zero_grads:
+            st.zeroed_by_step.update(upd)
         st.refresh_T(upd)                      # W^T copies of what was just updated
         st.refresh_planes(upd)                 # ... and its tiled bf16 planes (row-panel GEMM)
 
