@@ -22,7 +22,7 @@ for M, K in ((25600, 1024), (25600, 512)):
         ops.panel_gemm(x, pl.ref(0), y, 256, bias=b, R=R)
     torch.cuda.synchronize()
     s = buf.view(nwg, 16, 8).double().cpu()
-    names = ["wait vmcnt", "barrier", "dma issue", "lds -> A there", "split -> W there", "mfma issue", "total", "epilogue"]
+    names = ["wait A frags", "split -> W half 0", "wait vmcnt", "barrier", "issue reads + dma", "mfma h0 -> reads back", "total", "epilogue"]
     ng = K // 32
     print("M=%d K=%d: %d groups; mean cycles per wave (s_memtime ticks), per group in brackets; min / max over waves of the total: %.0f / %.0f" % (M, K, ng, float(s[:, :, 6].min()), float(s[:, :, 6].max())))
     for k in range(8):

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(1024, 4) void kpanel_kernel(const PanelParams p) {
     const int m_wave = m_wg + 32 * rg;
     const int KG = p.K >> 5;                              // groups = k-steps of the planes
 #ifdef PANEL_STAMPS
-    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // 0 wait vmcnt, 1 barrier, 2 DMA issue, 3 LDS reads -> activations there, 4 split -> weights there, 5 MFMA issue, 6 total, 7 epilogue
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // 0 wait for the activations, 1 split -> first weights there, 2 wait vmcnt, 3 barrier, 4 issue of reads + DMA, 5 first-half MFMAs -> all reads back, 6 total, 7 epilogue
     const unsigned long long t_begin = panel_stamp();
 #endif
     const uint32_t rbase = p.drop_thresh ? rng_stream_base(p.seed, p.stream) : 0u;
@@ -640,34 +640,35 @@ __global__ __launch_bounds__(1024, 4) void kpanel_kernel(const PanelParams p) {
     }
     const uint32_t aring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)aring;
     const uint32_t wring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem + (uint32_t)(lane16 + (4 * ch) * PSUB);
+    // Software pipeline over half groups: the LDS reads of group kg + 1 are issued right behind its barrier and are served while the MFMAs
+    // of the second half of group kg run (s_memtime stamps of the first, unpipelined loop: of 3 080 ticks per group a wave spent 850
+    // waiting for its fragments -- all 16 waves ask the LDS for 12 KB each at the same moment -- 430 issuing DMAs in front of those
+    // reads and 890 at the barrier; the 24 MFMAs took 260).
+    f32x4 raw[2][2];
+    bf16x8_t b0h[2], b0l[2], b1h[2], b1l[2];             // weight fragments of column tiles 0, 1 (b0) and 2, 3 (b1)
+    bf16x8_t ah[2], al[2];
+#define KP_READ_A(slot_) do { const uint32_t ab = aring_lds + (uint32_t)(slot_) * ASLOT; \
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7" \
+                     : "=&v"(raw[0][0]), "=&v"(raw[0][1]), "=&v"(raw[1][0]), "=&v"(raw[1][1]) \
+                     : "v"(ab + a_rd[0][0]), "v"(ab + a_rd[0][1]), "v"(ab + a_rd[1][0]), "v"(ab + a_rd[1][1]) : "memory"); } while (0)
+#define KP_READ_W0(slot_) do { const uint32_t wb = wring_lds + (uint32_t)(slot_) * WSLOT; \
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16384\n\tds_read_b128 %2, %4 offset:1024\n\tds_read_b128 %3, %4 offset:17408" \
+                     : "=&v"(b0h[0]), "=&v"(b0l[0]), "=&v"(b0h[1]), "=&v"(b0l[1]) : "v"(wb) : "memory"); } while (0)
+#define KP_READ_W1(slot_) do { const uint32_t wb = wring_lds + (uint32_t)(slot_) * WSLOT; \
+        asm volatile("ds_read_b128 %0, %4 offset:2048\n\tds_read_b128 %1, %4 offset:18432\n\tds_read_b128 %2, %4 offset:3072\n\tds_read_b128 %3, %4 offset:19456" \
+                     : "=&v"(b1h[0]), "=&v"(b1l[0]), "=&v"(b1h[1]), "=&v"(b1l[1]) : "v"(wb) : "memory"); } while (0)
+    // (the waits carry the registers as operands: to the compiler an asm's outputs are ready when the statement ends, and it moved the
+    // conversions and the first MFMAs ahead of a bare s_waitcnt)
     int slot = 0;
+    if (KG > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // group 0 is in LDS
+    KP_READ_A(0);
+    KP_READ_W0(0);
+    if (KG > 2) issue_group(2, 2);
     for (int kg = 0; kg < KG; ++kg) {
-        // outstanding vector-memory operations of this wave: group kg (3) and, if it exists, group kg + 1 (3)
         STAMP(ta);
-        if (kg + 1 < KG) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]) :: "memory");
         STAMP(tb);
-        __builtin_amdgcn_s_barrier();                     // every wave's share of group kg is in LDS, and nobody reads group kg - 1 (the slot refilled next) any more
-        STAMP(tc);
-        if (kg + 2 < KG) issue_group(kg + 2, slot == 0 ? 2 : slot - 1);
-        STAMP(td);
-        // (inline asm reads: before an ordinary LDS read hipcc waits vmcnt(0) for the LDS-DMA it believes may alias it)
-        f32x4 raw[2][2];
-        {
-            const uint32_t ab = aring_lds + (uint32_t)slot * ASLOT;
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
-                         : "=&v"(raw[0][0]), "=&v"(raw[0][1]), "=&v"(raw[1][0]), "=&v"(raw[1][1])
-                         : "v"(ab + a_rd[0][0]), "v"(ab + a_rd[0][1]), "v"(ab + a_rd[1][0]), "v"(ab + a_rd[1][1]) : "memory");
-        }
-        const uint32_t wb = wring_lds + (uint32_t)slot * WSLOT;
-        bf16x8_t bh[4], bl[4];
-        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16384\n\tds_read_b128 %2, %8 offset:1024\n\tds_read_b128 %3, %8 offset:17408\n\t"
-                     "ds_read_b128 %4, %8 offset:2048\n\tds_read_b128 %5, %8 offset:18432\n\tds_read_b128 %6, %8 offset:3072\n\tds_read_b128 %7, %8 offset:19456"
-                     : "=&v"(bh[0]), "=&v"(bl[0]), "=&v"(bh[1]), "=&v"(bl[1]), "=&v"(bh[2]), "=&v"(bl[2]), "=&v"(bh[3]), "=&v"(bl[3]) : "v"(wb) : "memory");
-        // (the waits carry the registers as operands: to the compiler an asm's outputs are ready when the statement ends, and it had moved the
-        // conversions and the first MFMAs ahead of a bare s_waitcnt)
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]) :: "memory");
-        STAMP(te);
-        bf16x8_t ah[2], al[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             u32x2 h0, l0, h1, l1;
@@ -676,23 +677,53 @@ __global__ __launch_bounds__(1024, 4) void kpanel_kernel(const PanelParams p) {
             ah[rt] = __builtin_bit_cast(bf16x8_t, (u32x4){h0[0], h0[1], h1[0], h1[1]});
             al[rt] = __builtin_bit_cast(bf16x8_t, (u32x4){l0[0], l0[1], l1[0], l1[1]});
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]), "+v"(bh[2]), "+v"(bl[2]), "+v"(bh[3]), "+v"(bl[3]) :: "memory");
-        STAMP(tf);
+        KP_READ_W1(slot);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b0h[0]), "+v"(b0l[0]), "+v"(b0h[1]), "+v"(b0l[1]) :: "memory");
+        STAMP(tc);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                acc[rt][ct] = mfma16(bl[ct], ah[rt], acc[rt][ct]);
-                acc[rt][ct] = mfma16(bh[ct], al[rt], acc[rt][ct]);
-                acc[rt][ct] = mfma16(bh[ct], ah[rt], acc[rt][ct]);
+                acc[rt][ct] = mfma16(b0l[ct], ah[rt], acc[rt][ct]);
+                acc[rt][ct] = mfma16(b0h[ct], al[rt], acc[rt][ct]);
+                acc[rt][ct] = mfma16(b0h[ct], ah[rt], acc[rt][ct]);
+            }
+        // (pins the twelve MFMAs above in front of the wait below: otherwise hipcc sinks most of them behind it)
+        asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[0][1]), "v"(acc[1][1]));
+        // every LDS read of this group's slots has returned before the wave meets the others: the slots are refilled behind the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1h[0]), "+v"(b1l[0]), "+v"(b1h[1]), "+v"(b1l[1]) :: "memory");
+        STAMP(td);
+        if (kg + 1 < KG) {
+            // outstanding vector-memory operations of this wave: group kg + 1 (3) and, if it exists, group kg + 2 (3)
+            if (kg + 2 < KG) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(te);
+            __builtin_amdgcn_s_barrier();                 // every wave's share of group kg + 1 is in LDS, and nobody reads group kg's slots any more
+            STAMP(tf);
+            const int nslot = slot == 2 ? 0 : slot + 1;
+            KP_READ_A(nslot);
+            KP_READ_W0(nslot);
+            if (kg + 3 < KG) issue_group(kg + 3, slot);
+            STAMP(tg);
+            STAMP_ADD(2, td, te); STAMP_ADD(3, te, tf); STAMP_ADD(4, tf, tg);
+            slot = nslot;
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                acc[rt][2 + ct] = mfma16(b1l[ct], ah[rt], acc[rt][2 + ct]);
+                acc[rt][2 + ct] = mfma16(b1h[ct], al[rt], acc[rt][2 + ct]);
+                acc[rt][2 + ct] = mfma16(b1h[ct], ah[rt], acc[rt][2 + ct]);
             }
 #ifdef PANEL_STAMPS
         asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][3]));        // the stamp below is taken when the last MFMA has ISSUED, not retired
 #endif
-        STAMP(tg);
-        STAMP_ADD(0, ta, tb); STAMP_ADD(1, tb, tc); STAMP_ADD(2, tc, td); STAMP_ADD(3, td, te); STAMP_ADD(4, te, tf); STAMP_ADD(5, tf, tg);
-        slot = slot == 2 ? 0 : slot + 1;
+        STAMP(th);
+        STAMP_ADD(0, ta, tb); STAMP_ADD(1, tb, tc); STAMP_ADD(5, tc, td);
     }
+#undef KP_READ_A
+#undef KP_READ_W0
+#undef KP_READ_W1
 #ifdef PANEL_STAMPS
     const unsigned long long t_loop = panel_stamp();
 #endif
