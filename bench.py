@@ -500,7 +500,9 @@ def main():
                                       (" + %d cross-model sub-step(s) with K/V-cached generation (NOT the headline configuration)" % a.cm_steps) if a.cm_steps else ""),
                       "global_batch": B * world, "parallelism": "dp%d" % world,
                       "precision": "split-bf16 (hi/lo) MFMA operands, fp32 accumulate and fp32 activations" if config.NSPLIT == 3 else "bf16 MFMA operands, fp32 accumulate"},
-           "graph_replay": (next(iter(stepper.graphs.values())).plan_info if (stepper is not None and stepper.graphs) else None),
+           "graph_replay": (dict(next(iter(stepper.graphs.values())).plan_info,
+                                 **{k: v for k, v in stepper.cache_report()["per_capture"][0].items() if k in ("capture_ms", "replays", "replay_host_ms", "eager_host_ms")})
+                            if (stepper is not None and stepper.graphs) else None),
            "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
            "losses_finite": finite, "last_losses": {k: round(v, 5) for k, v in last.items()},
            "roofline": roofline}

@@ -42,6 +42,7 @@ struct Plan {
     std::vector<hipEvent_t> events;
     hipEvent_t begin = nullptr;
     std::vector<hipEvent_t> ends;
+    std::vector<hipEvent_t> ar_done;   // one per OP_ALLREDUCE, in plan order: the next collective waits for the previous one (one communicator, one collective at a time)
     int kernels = 0, memsets = 0, memcpys = 0, cross_edges = 0, allreduces = 0;
     int64_t comm = 0;           // RCCL communicator (unast_comm_init) the plan's collectives are issued on
 };
@@ -143,6 +144,8 @@ extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
     for (size_t i = 0; i < plan->events.size() && ok; ++i) ok = hipEventCreateWithFlags(&plan->events[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&plan->begin, hipEventDisableTiming) == hipSuccess;
     for (int t = 0; t < nstreams && ok; ++t) ok = hipEventCreateWithFlags(&plan->ends[t], hipEventDisableTiming) == hipSuccess;
+    plan->ar_done.assign((size_t)plan->allreduces, nullptr);
+    for (size_t i = 0; i < plan->ar_done.size() && ok; ++i) ok = hipEventCreateWithFlags(&plan->ar_done[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) { unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_LAUNCH, "unast_graph_plan_create: stream / event creation failed"); return 0; }
     return (int64_t)(intptr_t)plan;
 }
@@ -173,6 +176,8 @@ extern "C" int unast_graph_plan_replay(int64_t handle, hipStream_t origin) {
     // everything enqueued on the caller's stream so far happens before the plan; the caller's stream waits for all of it at the end
     if (hipEventRecord(plan->begin, origin) != hipSuccess) return unast_set_error(UNAST_ERR_LAUNCH, "unast_graph_plan_replay: hipEventRecord failed");
     for (auto s : plan->streams) hipStreamWaitEvent(s, plan->begin, 0);
+    size_t ar_i = 0;
+    int ar_prev_stream = -1;
     for (const PlanOp& op : plan->ops) {
         hipStream_t s = plan->streams[op.stream];
         hipError_t e = hipSuccess;
@@ -186,7 +191,17 @@ extern "C" int unast_graph_plan_replay(int64_t handle, hipStream_t origin) {
             case OP_MEMCPY: e = hipMemcpyAsync(op.cdst, op.csrc, op.cbytes, op.ckind, s); break;
             case OP_RECORD: e = hipEventRecord(plan->events[op.event], s); break;
             case OP_WAIT: e = hipStreamWaitEvent(s, plan->events[op.event], 0); break;
-            case OP_ALLREDUCE: { const int rc = unast_allreduce(plan->comm, op.rbuf, op.rcount, s); if (rc) return rc; break; }
+            case OP_ALLREDUCE: {
+                // Collectives of one RCCL communicator must not run concurrently nor in an order that differs between ranks: whatever streams
+                // the layout put them on, each waits for the one issued before it (plan order is the same on every rank: same capture).
+                if (ar_i > 0 && ar_prev_stream != op.stream) e = hipStreamWaitEvent(s, plan->ar_done[ar_i - 1], 0);
+                if (e != hipSuccess) break;
+                const int rc = unast_allreduce(plan->comm, op.rbuf, op.rcount, s);
+                if (rc) return rc;
+                e = hipEventRecord(plan->ar_done[ar_i], s);
+                ar_prev_stream = op.stream; ++ar_i;
+                break;
+            }
             default: break;
         }
         if (e != hipSuccess) return unast_set_error(UNAST_ERR_LAUNCH, "unast_graph_plan_replay: op kind %d failed: %s", op.kind, hipGetErrorString(e));
@@ -205,6 +220,7 @@ extern "C" int unast_graph_plan_destroy(int64_t handle) {
     for (auto e : plan->events) if (e) hipEventDestroy(e);
     if (plan->begin) hipEventDestroy(plan->begin);
     for (auto e : plan->ends) if (e) hipEventDestroy(e);
+    for (auto e : plan->ar_done) if (e) hipEventDestroy(e);
     delete plan;
     return UNAST_OK;
 }

@@ -52,6 +52,7 @@ class _Native:
     handle = 0              # unast_comm_init communicator of this process (0: none)
     tried = False
     issued = 0              # collectives issued through it (tests)
+    last = None             # event behind the newest collective: the next one waits for it (see _issue)
 
 
 def native_comm():
@@ -216,12 +217,23 @@ def _issue(store, label, rng, overlap):
                 if c != s:
                     s.wait_stream(c)
         with torch.cuda.stream(s):
+            # One communicator, one collective at a time: the buckets are issued from several streams (the companions of the text and of
+            # the speech side, the discriminator's), and two collectives of one RCCL communicator that run concurrently -- or in a
+            # different order on another rank -- deadlock or corrupt its channels.  Each one therefore waits for the event behind the
+            # previous one; the host-side issue order is the same on every rank.  Under capture only markers are left (no events: extra
+            # side-to-side waits and events that die inside a capture are what takes hipStreamEndCapture down on ROCm 7.2, engine._ViaOrigin);
+            # the stream-replay executor chains the collectives of a plan itself (csrc/graph_exec.cpp).
             if torch.cuda.is_current_stream_capturing():
                 check(lib().unast_allreduce_marker(buf.data_ptr(), buf.numel(), ops._stream()), "unast_allreduce_marker")
+                if s != cur:
+                    _State.pending.append(s.record_event())
             else:
+                if _Native.last is not None:
+                    s.wait_event(_Native.last)
                 check(lib().unast_allreduce(h, buf.data_ptr(), buf.numel(), ops._stream()), "unast_allreduce")
-            if s != cur:
-                _State.pending.append(s.record_event())
+                _Native.last = s.record_event()
+                if s != cur:
+                    _State.pending.append(_Native.last)
         _Native.issued += 1
         _State.issued.append(rng)
         _State.log.append((label, a, b))
