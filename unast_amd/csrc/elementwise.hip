@@ -355,6 +355,24 @@ extern "C" int unast_scale_inplace(float* a, float alpha, int64_t n, hipStream_t
     return unast_check_launch("unast_scale_inplace");
 }
 
+// The teacher-forced decoder input of SpeechTransformer.decode_sequence (src/network.py:254-262): dst[b, 0, :] = 0 (the "go" frame),
+// dst[b, t, :] = src[b, t - 1, :].  n4 = T * M / 4 float4 per sequence.
+__global__ __launch_bounds__(256) void shift_frames_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int B, size_t n4, int m4) {
+    const size_t total = (size_t)B * n4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t in = i % n4;
+        dst[i] = in < (size_t)m4 ? make_float4(0.f, 0.f, 0.f, 0.f) : src[i - m4];
+    }
+}
+
+extern "C" int unast_shift_frames(const float* src, float* dst, int B, int T, int M, hipStream_t stream) {
+    UNAST_REQUIRE(src && dst && B > 0 && T > 0 && M > 0 && (M & 3) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0,
+                  "unast_shift_frames: needs M %% 4 == 0 and 16-byte aligned buffers");
+    const size_t n4 = (size_t)T * (M / 4);
+    hipLaunchKernelGGL(shift_frames_kernel, dim3(ew_grid((size_t)B * n4)), dim3(256), 0, stream, (const float4*)src, (float4*)dst, B, n4, M / 4);
+    return unast_check_launch("unast_shift_frames");
+}
+
 extern "C" int unast_add_strided(float* dst, int ldd, const float* src, int lds, int rows, int cols, hipStream_t stream) {
     UNAST_REQUIRE(dst && src && rows > 0 && cols > 0 && ldd >= cols && lds >= cols, "unast_add_strided: bad arguments");
     hipLaunchKernelGGL(add_strided_kernel, dim3(ew_grid((size_t)rows * cols)), dim3(256), 0, stream, dst, ldd, src, lds, rows, cols);

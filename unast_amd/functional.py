@@ -437,8 +437,11 @@ def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk, shift=True, postnet
     a = m.args
     N = B * T
     if shift:
-        tgt = torch.zeros_like(mel)                                # [zero frame, mel[:-1]]  (device-memory plumbing)
-        tgt[:, 1:] = mel[:, :-1]
+        if M % 4 == 0 and mel.is_contiguous() and mel.data_ptr() % 16 == 0:
+            tgt = ops.shift_frames(mel, torch.empty_like(mel))      # [zero frame, mel[:-1]] in one launch
+        else:
+            tgt = torch.zeros_like(mel)
+            tgt[:, 1:] = mel[:, :-1]
     else:
         tgt = mel.contiguous()
     x = speech_prenet(cx, tape, m, tgt.view(N, M), T)

@@ -93,6 +93,12 @@ class GraphedTrainStep:
         disc = shp("disc", a.d_steps) if a.use_discriminator else ()
         return gen, disc, (is_deterministic(), config.NSPLIT, self.model.training)
 
+    @staticmethod
+    def _static_like(batch, dev):
+        """Static buffers of one (text, mel, text_len, mel_len) batch; the lengths as int32, the form every kernel takes them in: the copy
+        into the buffer converts, and process_batch's own cast becomes a no-op inside the capture (6 launches per step)."""
+        return tuple(torch.empty(t.shape, dtype=(torch.int32 if (i >= 2 and not t.dtype.is_floating_point) else t.dtype), device=dev) for i, t in enumerate(batch))
+
     def _copy_in(self, dsts, srcs):
         for dst, src in zip(dsts, srcs):
             for d, s in zip(dst, src):
@@ -105,8 +111,7 @@ class GraphedTrainStep:
         st = self.static_gen.get(gen_sig)
         if st is None:
             a = self.args
-            st = self.static_gen[gen_sig] = {k: [tuple(torch.empty(t.shape, dtype=t.dtype, device=dev) for t in batches[k][i]) for i in range(n)]
-                                             for k, n in (("unsup", a.ae_steps), ("sup", a.sp_steps))}
+            st = self.static_gen[gen_sig] = {k: [self._static_like(batches[k][i], dev) for i in range(n)] for k, n in (("unsup", a.ae_steps), ("sup", a.sp_steps))}
         self.gen_sig = gen_sig
         self.static["unsup"], self.static["sup"] = st["unsup"], st["sup"]
         for k in ("unsup", "sup"):
@@ -117,7 +122,7 @@ class GraphedTrainStep:
         st = self.static_disc.get(disc_sig)
         if st is None:
             n = self.args.d_steps if self.args.use_discriminator else 0
-            st = self.static_disc[disc_sig] = [tuple(torch.empty(t.shape, dtype=t.dtype, device=dev) for t in batches["disc"][i]) for i in range(n)]
+            st = self.static_disc[disc_sig] = [self._static_like(batches["disc"][i], dev) for i in range(n)]
         self.disc_sig = disc_sig
         self.static["disc"] = st
         self._copy_in(st, batches["disc"])
@@ -233,7 +238,7 @@ class GraphedTrainStep:
             self._body(cap_losses)
             flat = [(k, v) for k, vs in cap_losses.items() for v in vs]
             rec.loss_keys = [k for k, _ in flat]
-            rec.loss_vec = torch.stack([v.reshape(()) for _, v in flat]) if flat else None
+            rec.loss_vec = [v.reshape(()) for _, v in flat] if flat else None       # scalars in the capture's memory: gathered after each replay
         try:
             rec.graph = _capture(fn, pool=self.pool, keep_graph=True)
         finally:
@@ -312,7 +317,7 @@ class GraphedTrainStep:
             rec.graph.replay()
         self.opt._step_count = getattr(self.opt, "_step_count", 0) + 1       # what torch's LR schedulers look at
         if rec.loss_vec is not None:
-            snap = rec.loss_vec.clone()
+            snap = torch.stack(rec.loss_vec)              # one launch: gathers and snapshots (the scalars are overwritten by the next replay)
             for i, k in enumerate(rec.loss_keys):
                 losses[k].append(snap[i])
         rec.replays += 1

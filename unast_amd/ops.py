@@ -572,6 +572,13 @@ def scale_inplace(a, alpha):
     check(lib().unast_scale_inplace(_p(a), float(alpha), a.numel(), _stream()), "unast_scale_inplace")
 
 
+def shift_frames(mel3d, out3d):
+    """out[b,0] = 0, out[b,t] = mel[b,t-1] (the decoder input of teacher forcing)."""
+    B, T, M = mel3d.shape
+    check(lib().unast_shift_frames(_p(mel3d), _p(out3d), B, T, M, _stream()), "unast_shift_frames")
+    return out3d
+
+
 def add_strided(dst2d, src2d, cols):
     """dst2d[:, :cols] += src2d[:, :cols] (row strides may differ)."""
     rows = dst2d.shape[0]
