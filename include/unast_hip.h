@@ -197,12 +197,14 @@ int unast_scalar_combine(const float* a, const float* b, const float* c, float d
  * doubles of workspace, zero on entry, left zero on exit.  (The train step's two masked MSEs come out of unast_speech_loss_*.) */
 int unast_masked_mse(const float* gold, const float* pred, const float* mask, int64_t n, double* ws3, float* out, hipStream_t stream);
 /* speech_loss (src/train.py:100-103, 113-122): head = [pre-net mel (M cols) | stop logit | pad] with row stride ldh.
- * fwd writes loss[0]; bwd writes d_head (same layout) and d_post scaled by the device scalar *gscale. ws: 3 doubles. */
+ * fwd writes loss[0] in ONE launch (the last workgroup to arrive forms the scalar); bwd writes d_head (same layout) and d_post scaled by
+ * the device scalar *gscale.  ws: 4 doubles, ZERO on entry, left zero on exit (no memset in front, one workspace serves call after call). */
 int unast_speech_loss_fwd(const float* gold, const float* head, int ldh, const float* post, const int* lens, int B, int T, int M,
                           float eos_weight, double* ws, float* loss, hipStream_t stream);
 int unast_speech_loss_bwd(const float* gold, const float* head, int ldh, const float* post, const int* lens, int B, int T, int M,
                           float eos_weight, const float* gscale, float* d_head, float* d_post, hipStream_t stream);
-/* text_loss (src/train.py:105-111): weighted CE, ignore_index 0, EOS(2) weight. ws: 2 doubles kept for the backward. */
+/* text_loss (src/train.py:105-111): weighted CE, ignore_index 0, EOS(2) weight; one launch forward.  ws: 4 doubles -- [0..2] zero on entry and
+ * left zero on exit, [3] receives the weight sum the backward of THIS call reads (keep ws untouched until then). */
 int unast_text_loss_fwd(const float* logits, int ldl, const int64_t* gold, int rows, int V, float eos_weight,
                         double* ws, float* loss, hipStream_t stream);
 int unast_text_loss_bwd(const float* logits, int ldl, const int64_t* gold, int rows, int V, float eos_weight, const double* ws,

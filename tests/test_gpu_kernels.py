@@ -272,10 +272,13 @@ def test_losses_match_oracle():
     gold_stop = torch.nn.functional.one_hot(lens - 1, T).double()
     ref = R.speech_loss(gold.double(), gold_stop, hp, pp, lens, st, 5.0)
     (ref * 0.5).backward()
-    ws = torch.empty(4, dtype=torch.float64, device=D); loss = torch.empty(1, device=D)
+    ws = torch.zeros(4, dtype=torch.float64, device=D); loss = torch.empty(1, device=D)       # zero on entry, left zero on exit
     li = lens.to(torch.int32).to(D)
-    ops.speech_loss_fwd(gold.to(D), head.to(D), post.to(D), li, 5.0, ws, loss)
-    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    for _ in range(2):
+        loss.fill_(-1.0)
+        ops.speech_loss_fwd(gold.to(D), head.to(D), post.to(D), li, 5.0, ws, loss)
+        assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+        assert bool((ws.view(torch.int64) == 0).all())
     gs = torch.tensor([0.5], device=D); dh = torch.empty(B, T, 84, device=D); dp = torch.empty(B, T, M, device=D)
     ops.speech_loss_bwd(gold.to(D), head.to(D), post.to(D), li, 5.0, gs, dh, dp)
     assert relerr(dh[..., :80], hp.grad) < 1e-5 and relerr(dh[..., 80], st.grad) < 1e-5 and relerr(dp, pp.grad) < 1e-5
@@ -287,9 +290,12 @@ def test_losses_match_oracle():
     lr = logits[:, :V].clone().double().view(B, T, V).requires_grad_(True)
     ref = R.text_loss(text, lr, 3.0)
     (ref * 0.25).backward()
-    ws2 = torch.empty(2, dtype=torch.float64, device=D)
-    ops.text_loss_fwd(logits.to(D), text.to(D).view(-1), V, 3.0, ws2, loss)
-    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    ws2 = torch.zeros(4, dtype=torch.float64, device=D)
+    for _ in range(2):
+        loss.fill_(-1.0)
+        ops.text_loss_fwd(logits.to(D), text.to(D).view(-1), V, 3.0, ws2, loss)
+        assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+        assert bool((ws2[:3].view(torch.int64) == 0).all()) and float(ws2[3]) > 0
     gs = torch.tensor([0.25], device=D); dl = torch.empty(B * T, 48, device=D)
     ops.text_loss_bwd(logits.to(D), text.to(D).view(-1), V, 3.0, ws2, gs, dl)
     assert relerr(dl[:, :V].reshape(B, T, V), lr.grad) < 1e-5 and (dl[:, V:] == 0).all()

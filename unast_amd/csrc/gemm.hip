@@ -603,6 +603,9 @@ static void launch_tile(const GemmParams& p, int nsplit, int wn, dim3 grid, hipS
     if (wn == 4) {
         if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 4, 2, FLAGS>), grid, dim3(512), 0, s, p);
         else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 4, 2, FLAGS>), grid, dim3(512), 0, s, p);
+    } else if (wn == 1) {      // 128x64 tile, 4 waves (4 along M): twice the workgroups of the 128x128 tile for outputs that leave the chip underfilled
+        if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 1, 4, FLAGS>), grid, dim3(256), 0, s, p);
+        else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 1, 4, FLAGS>), grid, dim3(256), 0, s, p);
     } else if (wn == 8) {      // 128x128 tile, 8 waves (4 along M x 2 along N): <=128 VGPRs, 4 waves/SIMD
         if (nsplit == 3) hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 3, 2, 4, FLAGS>), grid, dim3(512), 0, s, p);
         else             hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 1, 2, 4, FLAGS>), grid, dim3(512), 0, s, p);
@@ -615,7 +618,7 @@ static void launch_tile(const GemmParams& p, int nsplit, int wn, dim3 grid, hipS
 // for weight gradients); any other request falls back to the general kernel (flags & ~1) -- never to a wrong one.
 template <int AM, int BMODE, bool WEIGHT_B, bool PLAIN>
 static void launch_split(const GemmParams& p, int nsplit, int wn, int flags, dim3 grid, hipStream_t s) {
-    const bool fast_tile = (AM == OP_RC) ? (wn == 2) : (wn == 8);
+    const bool fast_tile = (AM == OP_RC) ? (wn == 2) : (wn == 8 || wn == 1);
     if constexpr (PLAIN) {
         if (fast_tile && (flags & 1)) {
             if constexpr (WEIGHT_B) { if (flags & 2) { launch_tile<AM, BMODE, 3>(p, nsplit, wn, grid, s); return; } }
@@ -666,13 +669,15 @@ extern "C" int unast_gemm(int a_mode, int b_mode, int nsplit,
     UNAST_REQUIRE(!out_split || ((N & 3) == 0 && (ldc & 3) == 0 && beta == 0 && splitk == 1), "unast_gemm: out_split needs N %% 4 == 0, ldc %% 4 == 0, beta = 0, no split-K");
     // tile width: 128x256 when N is wide enough and the grid still fills the chip; `tile_wn` (2/4) overrides, 0 = auto
     int wn = tile_wn;
-    if (wn != 2 && wn != 4 && wn != 8) {
+    if (wn != 1 && wn != 2 && wn != 4 && wn != 8) {
         // measured on MI355X (tools/bench_gemm.py): for forward / dgrad shapes the 128x128 tile shared by 8 waves
         // (<=128 VGPRs, 4 waves/SIMD) is 10-25 % faster than 4 waves (more waves to cover LDS/barrier/global latencies);
         // weight gradients (long K, split-K) are equal, the 128x256 tile only helps isolated large shapes.
         wn = (a_mode == OP_RC) ? 2 : 8;
+        // few row panels and a narrow output (the text side: 5 760 rows into 256 columns = 90 tiles of 128x128 on 256 CUs): 128x64 tiles
+        if (a_mode == OP_KC && splitk == 1 && (M + GBM - 1) / GBM * ((N + 127) / 128) <= 128 && N >= 128) wn = 1;
     }
-    const int gbn = (wn == 4) ? 256 : 128;
+    const int gbn = (wn == 4) ? 256 : (wn == 1) ? 64 : 128;
     p.tiles_m = (M + GBM - 1) / GBM; p.tiles_n = (N + gbn - 1) / gbn;
     int ksteps = (K + GBK - 1) / GBK;
     if (splitk > ksteps) splitk = ksteps;

@@ -5,10 +5,12 @@
 // Reductions are accumulated in double (wave shuffle -> one atomic per wave); the final scalar is fp32.
 #include "common.h"
 
-// ws layout (doubles): [0] sum mask*(gold-pre)^2  [1] sum mask*(gold-post)^2  [2] sum bce(stop)
-__global__ __launch_bounds__(256) void speech_loss_partial_kernel(const float* __restrict__ gold, const float* __restrict__ head, int ldh,
-                                                                  const float* __restrict__ post, const int* __restrict__ lens, int B, int T, int M,
-                                                                  float eos_weight, double* __restrict__ ws) {
+// ws layout (doubles): [0] sum mask*(gold-pre)^2  [1] sum mask*(gold-post)^2  [2] sum bce(stop)  [3] workgroups that have arrived.
+// ONE launch: ws is zero on entry; every workgroup adds its partial sums, the last one to arrive forms the loss and leaves ws zero again
+// (no memset node in front and no single-thread "final" launch behind it: both sat on the dependent chain between forward and backward).
+__global__ __launch_bounds__(256) void speech_loss_fwd_kernel(const float* __restrict__ gold, const float* __restrict__ head, int ldh,
+                                                              const float* __restrict__ post, const int* __restrict__ lens, int B, int T, int M,
+                                                              float eos_weight, double* __restrict__ ws, float* __restrict__ loss) {
     const int rows = B * T;
     const int mq = M >> 2;
     const size_t total = (size_t)rows * mq;
@@ -38,14 +40,19 @@ __global__ __launch_bounds__(256) void speech_loss_partial_kernel(const float* _
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = d0; red[threadIdx.x >> 6][1] = d1; red[threadIdx.x >> 6][2] = d2; }
     __syncthreads();
     if (threadIdx.x < 3) atomicAdd(ws + threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
-}
-
-__global__ void speech_loss_final_kernel(const double* __restrict__ ws, const int* __restrict__ lens, int B, int T, int M, float* __restrict__ loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double sl = 0.0;
-        for (int b = 0; b < B; ++b) sl += (double)lens[b];
-        const double denom = sl * (double)M;
-        loss[0] = (float)(ws[0] / denom + ws[1] / denom + ws[2] / ((double)B * T));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long*>(ws + 3), 1ull) + 1ull;
+        if (arrived == gridDim.x) {
+            __threadfence();
+            const double s0 = atomicAdd(ws + 0, 0.0), s1 = atomicAdd(ws + 1, 0.0), s2 = atomicAdd(ws + 2, 0.0);
+            double sl = 0.0;
+            for (int b = 0; b < B; ++b) sl += (double)lens[b];
+            const double denom = sl * (double)M;
+            loss[0] = (float)(s0 / denom + s1 / denom + s2 / ((double)B * T));
+            ws[0] = 0.0; ws[1] = 0.0; ws[2] = 0.0; reinterpret_cast<unsigned long long*>(ws)[3] = 0ull;
+        }
     }
 }
 
@@ -95,10 +102,11 @@ __global__ __launch_bounds__(256) void speech_loss_bwd_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Text loss: one thread per token (V = 46 logits).  ws doubles: [0] sum w*nll, [1] sum w.
+// Text loss: one thread per token (V = 46 logits).  ws doubles: [0] sum w*nll, [1] sum w, [2] workgroups arrived, [3] sum w of the LAST
+// call (what the backward reads).  One launch, as speech_loss_fwd_kernel: zero on entry, [0..2] zero again on exit.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void text_loss_partial_kernel(const float* __restrict__ logits, int ldl, const int64_t* __restrict__ gold, int rows, int V,
-                                                                int eos_idx, float eos_weight, int pad_idx, double* __restrict__ ws) {
+__global__ __launch_bounds__(256) void text_loss_fwd_kernel(const float* __restrict__ logits, int ldl, const int64_t* __restrict__ gold, int rows, int V,
+                                                            int eos_idx, float eos_weight, int pad_idx, double* __restrict__ ws, float* __restrict__ loss) {
     float a = 0.f, w = 0.f;
     for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
         const int y = (int)gold[r];
@@ -114,16 +122,24 @@ __global__ __launch_bounds__(256) void text_loss_partial_kernel(const float* __r
     }
     double da = wave_sum_d((double)a), dw = wave_sum_d((double)w);
     if ((threadIdx.x & 63) == 0) { atomicAdd(ws + 0, da); atomicAdd(ws + 1, dw); }
-}
-
-__global__ void text_loss_final_kernel(const double* __restrict__ ws, float* __restrict__ loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) loss[0] = (float)(ws[0] / ws[1]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long*>(ws + 2), 1ull) + 1ull;
+        if (arrived == gridDim.x) {
+            __threadfence();
+            const double s0 = atomicAdd(ws + 0, 0.0), s1 = atomicAdd(ws + 1, 0.0);
+            loss[0] = (float)(s0 / s1);
+            ws[3] = s1;
+            ws[0] = 0.0; ws[1] = 0.0; reinterpret_cast<unsigned long long*>(ws)[2] = 0ull;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void text_loss_bwd_kernel(const float* __restrict__ logits, int ldl, const int64_t* __restrict__ gold, int rows, int V,
                                                             int eos_idx, float eos_weight, int pad_idx, const double* __restrict__ ws,
                                                             const float* __restrict__ gscale, float* __restrict__ dlogits) {
-    const float k = gscale[0] / (float)ws[1];
+    const float k = gscale[0] / (float)ws[3];
     for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
         const int y = (int)gold[r];
         float* dr = dlogits + (size_t)r * ldl;
@@ -184,13 +200,11 @@ static int ls_grid(size_t work, int cap = 1024) {
 }
 
 extern "C" int unast_speech_loss_fwd(const float* gold, const float* head, int ldh, const float* post, const int* lens, int B, int T, int M,
-                                     float eos_weight, double* ws /* 3 doubles */, float* loss, hipStream_t stream) {
+                                     float eos_weight, double* ws /* 4 doubles, zero on entry, zero on exit */, float* loss, hipStream_t stream) {
     UNAST_REQUIRE(gold && head && post && lens && ws && loss, "unast_speech_loss_fwd: null pointer");
     UNAST_REQUIRE(B > 0 && T > 0 && (M & 3) == 0 && ldh > M && (ldh & 3) == 0, "unast_speech_loss_fwd: need M%%4==0 and ldh>M, ldh%%4==0");
-    hipMemsetAsync(ws, 0, 3 * sizeof(double), stream);
-    hipLaunchKernelGGL(speech_loss_partial_kernel, dim3(ls_grid((size_t)B * T * (M / 4), 512)), dim3(256), 0, stream, gold, head, ldh, post, lens, B, T, M,
-                       eos_weight, ws);
-    hipLaunchKernelGGL(speech_loss_final_kernel, dim3(1), dim3(64), 0, stream, ws, lens, B, T, M, loss);
+    hipLaunchKernelGGL(speech_loss_fwd_kernel, dim3(ls_grid((size_t)B * T * (M / 4), 512)), dim3(256), 0, stream, gold, head, ldh, post, lens, B, T, M,
+                       eos_weight, ws, loss);
     return unast_check_launch("unast_speech_loss_fwd");
 }
 
@@ -204,11 +218,9 @@ extern "C" int unast_speech_loss_bwd(const float* gold, const float* head, int l
 }
 
 extern "C" int unast_text_loss_fwd(const float* logits, int ldl, const int64_t* gold, int rows, int V, float eos_weight,
-                                   double* ws /* 2 doubles, kept for bwd */, float* loss, hipStream_t stream) {
+                                   double* ws /* 4 doubles: [0..2] zero on entry and on exit, [3] kept for bwd */, float* loss, hipStream_t stream) {
     UNAST_REQUIRE(logits && gold && ws && loss && rows > 0 && V > 0 && ldl >= V, "unast_text_loss_fwd: bad arguments");
-    hipMemsetAsync(ws, 0, 2 * sizeof(double), stream);
-    hipLaunchKernelGGL(text_loss_partial_kernel, dim3(ls_grid(rows)), dim3(256), 0, stream, logits, ldl, gold, rows, V, 2, eos_weight, 0, ws);
-    hipLaunchKernelGGL(text_loss_final_kernel, dim3(1), dim3(64), 0, stream, ws, loss);
+    hipLaunchKernelGGL(text_loss_fwd_kernel, dim3(ls_grid(rows)), dim3(256), 0, stream, logits, ldl, gold, rows, V, 2, eos_weight, 0, ws, loss);
     return unast_check_launch("unast_text_loss_fwd");
 }
 

@@ -104,12 +104,34 @@ class _LossSum(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        one = _ONES.get(g.device)
+        if one is not None and g.data_ptr() == one.data_ptr():      # seeded by _sum_and_backward: d loss / d part = 1 / div, a resident constant
+            key = (g.device, ctx.div)
+            gg = _INV.get(key)
+            if gg is None:
+                gg = _INV[key] = torch.full((), 1.0, dtype=torch.float32, device=g.device) / ctx.div
+            return (None,) + (gg,) * ctx.n
         gg = torch.empty((), dtype=torch.float32, device=g.device)
         ops.scalar_combine([g.contiguous()], ctx.div, gg)
         return (None,) + (gg,) * ctx.n
 
 
 _ONES = {}
+_INV = {}
+_WS_RING = {}
+
+
+def _loss_ws(dev):
+    """Four zeroed doubles for one loss call: the loss kernels take their workspace zero and leave it zero (csrc/loss.hip), so the slots of
+    a small ring are handed out round-robin and never filled again; a slot comes back after 64 calls, long after its call's backward (the
+    text loss keeps its weight sum in slot word 3 until then)."""
+    ring = _WS_RING.get(dev)
+    if ring is None:
+        ring = _WS_RING[dev] = [torch.zeros(64, 4, dtype=torch.float64, device=dev), 0]
+    i = ring[1]
+    ring[1] = (i + 1) % 64
+    return ring[0][i]
+
 
 
 def _sum_and_backward(parts, accum_steps):
@@ -158,7 +180,7 @@ def text_loss(gold_char, text_pred, eos_weight=1.0):
 
     def fwd(loss):
         logits = _as_padded(lg_btv.detach(), B * T, ldl, V)
-        ws = torch.empty(2, dtype=torch.float64, device=loss.device)
+        ws = _loss_ws(loss.device)
         ops.text_loss_fwd(logits, gold, V, float(eos_weight), ws, loss)
         return logits, ws
 
@@ -190,7 +212,7 @@ def speech_loss(gold_mel, stop_label, pred_mel, post_pred_mel, mel_len, stop_pre
             head[:, :M].copy_(pm.reshape(B * T, M))
             head[:, M].copy_(sp.reshape(B * T))
         post = post_pred_mel.detach().contiguous()
-        ws = torch.empty(4, dtype=torch.float64, device=loss.device)
+        ws = _loss_ws(loss.device)
         ops.speech_loss_fwd(gold, head.view(B, T, ldh), post, lens, float(eos_weight), ws, loss)
         return head, post
 
