@@ -168,6 +168,7 @@ __global__ __launch_bounds__(128 * (4 / QS), (QS == 1 ? 4 : 2)) void attn_q_kern
     const int h = bh % p.H, b = bh / p.H;
     const int qblk = bx * 128;
     const int q0 = qblk + wave * 16 * QS;
+    const bool wave_live = __builtin_amdgcn_readfirstlane((int)(q0 < p.Tq)) != 0;
     const int klen = p.lens_k ? min(p.Tk, p.lens_k[b]) : p.Tk;
     int kmax = klen;
     if (p.causal) kmax = min(kmax, qblk + 128);
@@ -240,6 +241,9 @@ __global__ __launch_bounds__(128 * (4 / QS), (QS == 1 ? 4 : 2)) void attn_q_kern
             tile_load<64, NT>(Kb + (size_t)kr * p.ldk, p.ldk, min(64, p.Tk - kr), rk, t);
             tile_load<64, NT>(Vb + (size_t)kr * p.ldv, p.ldv, min(64, p.Tk - kr), rv, t);
         }
+        // A wave whose queries all lie past Tq (the overhang of the last 128-query block: three of four waves at Tq = 800) keeps loading,
+        // storing and meeting the barriers, and skips the products and the softmax.
+        if (wave_live) {
         // ---- S^T[key,q] (and dP^T in dQ mode) -----------------------------------------------------------
         f32x4 s[4][QS], dp[4][QS];
 #pragma unroll
@@ -352,6 +356,7 @@ __global__ __launch_bounds__(128 * (4 / QS), (QS == 1 ? 4 : 2)) void attn_q_kern
                 for (int qs = 0; qs < QS; ++qs) o[dt][qs] = mma3<NSPLIT>(xh, xl, pf[qs][0], pf[qs][PARTS - 1], o[dt][qs]);
             }
         }
+        }   // wave_live
         __syncthreads();
     }
 
@@ -400,6 +405,12 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
     const int kblk = bx * 128;
     const int k0 = kblk + wave * 32;
     const int klen = p.lens_k ? min(p.Tk, p.lens_k[b]) : p.Tk;
+    // A wave whose 32 keys are all masked (the tail of a sequence shorter than the block: lengths are ragged) contributes nothing: it
+    // keeps loading, storing, meeting the barriers and taking its share of the dQ product, and skips S, dP, the pointwise phase and
+    // the dK / dV products; its accumulators stay zero (what the epilogue writes for masked keys).  The dQ product then covers the
+    // live 32-key chunks of the block only (the dead waves' rows of the dS image are never written).
+    const bool wave_live = __builtin_amdgcn_readfirstlane((int)(k0 < klen)) != 0;
+    const int kk_live = min(4, (max(klen - kblk, 0) + 31) >> 5);
     const float sc = p.scale * LOG2E;
     const float* Qb = p.Q + (size_t)b * p.Tq * p.ldq + h * HD;
     const float* Kb = p.K + (size_t)b * p.Tk * p.ldk + h * HD;
@@ -461,6 +472,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
         f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
+            if (kk >= kk_live) break;                     // (workgroup-uniform)
             const bf16x8_t bh = tr_frag(sKs[0], 32 * kk, 16 * wave, l15, g);
             const bf16x8_t bl = (PARTS == 2) ? tr_frag(sKs[PARTS - 1], 32 * kk, 16 * wave, l15, g) : bh;
 #pragma unroll
@@ -483,6 +495,9 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
         tile_store<32, NSPLIT>(rq, sQ[0], sQ[PARTS - 1], t, split_in);
         tile_store<32, NSPLIT>(rd, sD[0], sD[PARTS - 1], t, split_in);
         rl_cur = rl * stat_mul;
+        // dropout row keys of the tile's 32 queries: lane L hashes query L & 31 ONCE; the pointwise phase fetches its eight rows by lane
+        // shuffle (eight pcg hashes per lane and iteration before: 112 of the loop's ~1 000 vector issue slots)
+        const uint32_t rk_cur = p.drop_thresh ? pcg_hash((uint32_t)(((size_t)b * p.H + h) * p.Tq + qt * 32 + (lane & 31)) + rbase) : 0u;
         __syncthreads();
         if (FUSE_DQ && qt > qt_begin) dq_phase(qt - 1, (qt - 1) & 1);
         if (qt + 1 < qt_end) {
@@ -491,6 +506,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
             tile_load<32>(dOb + (size_t)qr * p.lddo, p.lddo, min(32, p.Tq - qr), rd, t);
             stat_load(qt + 1);
         }
+        if (wave_live) {
         // ---- S[q,key], dP[q,key] --------------------------------------------------------------------------
         f32x4 s[2][2], dp[2][2];
 #pragma unroll
@@ -532,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
                     const bool qok = !MASKED || q < p.Tq;
                     const float l2 = __shfl(rl_cur, 16 * qs + 4 * g + r, 64);
                     const float de = __shfl(rl_cur, 32 + 16 * qs + 4 * g + r, 64);
-                    const uint32_t rkey = p.drop_thresh ? pcg_hash((uint32_t)(((size_t)b * p.H + h) * p.Tq + q) + rbase) : 0u;
+                    const uint32_t rkey = p.drop_thresh ? (uint32_t)__shfl((int)rk_cur, 16 * qs + 4 * g + r, 64) : 0u;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         const int key = k0 + 16 * ks + l15;
@@ -585,6 +601,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
                 dk[dt][ks] = mma3<NSPLIT>(qh, ql, sf[ks][0], sf[ks][PARTS - 1], dk[dt][ks]);
             }
         }
+        }   // wave_live
         __syncthreads();
     }
     if (FUSE_DQ && qt_begin < qt_end) dq_phase(qt_end - 1, (qt_end - 1) & 1);
