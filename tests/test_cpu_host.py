@@ -294,3 +294,26 @@ def test_replay_planner_under_address_sanitizer(tmp_path):
     assert "all cases passed" in r.stdout
     src = open(os.path.join(root, "unast_amd", "csrc", "graph_exec.cpp")).read()
     assert "unast_layout::plan_layout" in src, "the executor must plan through the tested header"
+
+
+def test_weight_plane_plan_geometry():
+    """unast_amd.planes (no arithmetic, no GPU): which destination matrices get tiled planes, their padded extents and the 64 x 64 block
+    descriptors unast_retile_weights consumes."""
+    from unast_amd import planes
+    assert planes.eligible(1024, 256) and planes.eligible(81, 256) and planes.eligible(256, 80) and planes.eligible(512, 128)
+    assert not planes.eligible(256, 255) and not planes.eligible(256, 228) and planes.eligible(256, 224) is False      # K % 4; 224 < K < 256; 7 k-steps are not built
+    assert planes.eligible(256, 1024) and planes.eligible(256, 768) and planes.eligible(512, 512)      # K-streamed form: K % 64 == 0 into 256-column tiles
+    assert not planes.eligible(81, 1024) and not planes.eligible(256, 1000)
+    ks, pb = planes.geometry(81, 256)
+    assert (ks, pb) == (8, 128 * 8 * 64)                                                  # 81 rows padded to 128, 8 k-steps, 64 B per (row, k-step)
+    ks, pb = planes.geometry(256, 1024)
+    assert (ks, pb) == (32, 256 * 32 * 64)
+    descs, placed, total = planes.plan([(0, 256, 0, 81, 256), (81 * 256, 1024, 1, 1024, 256), (0, 1024, 0, 256, 1024)])
+    assert descs.dtype.itemsize == 48
+    # blocks: ceil64(N) / 64 x ceil(ksteps * 32 / 64)
+    assert len(descs) == 2 * 4 + 16 * 4 + 4 * 16
+    assert placed[0][0] == 0 and placed[1][0] == 2 * placed[0][1] and placed[2][0] == placed[1][0] + 2 * placed[1][1]
+    assert total == placed[2][0] + 2 * placed[2][1]
+    d = descs[8]                                                                            # first block of the transposed matrix
+    assert (int(d["src_off"]), int(d["ld"]), int(d["transposed"]), int(d["N"]), int(d["K"]), int(d["n0"]), int(d["k0"])) == (81 * 256, 1024, 1, 1024, 256, 0, 0)
+    assert int(d["dst_off"]) == placed[1][0] and int(d["plane_bytes"]) == placed[1][1]

@@ -886,6 +886,7 @@ extern "C" int unast_panel_gemm(const float* A, int lda, const void* w_planes, i
     // vector epilogue operands must be 16-byte addressable
     UNAST_REQUIRE((ldc & 3) == 0 || !out_split, "unast_panel_gemm: ldc");
     const int ksteps = (K + 31) / 32;
+    UNAST_REQUIRE(ksteps != 8 || K == 256, "unast_panel_gemm: 224 < K < 256 is not built (the 8-k-step form copies whole 1-KB activation rows by LDS-DMA; K=%d)", K);
     const int rt = rows_per_wg ? rows_per_wg : (M >= 16384 ? 128 : 64);
     switch (ksteps) {
         case 8: panel_launch<8>(p, rt, ln, stream); break;

@@ -26,6 +26,8 @@ def geometry(N, K):
 def eligible(N, K):
     if K > MAX_K:                              # the K-streamed form of the kernel: 64-deep groups of K into 256-column output tiles
         return K % 64 == 0 and K <= 8192 and N % 256 == 0
+    if 224 < K < 256:                          # the 8-k-step form takes its activation rows by LDS-DMA as whole 1-KB rows: K = 256 exactly
+        return False
     return 4 <= K <= MAX_K and K % 4 == 0 and (K + 31) // 32 in KSTEPS_BUILT and N >= 1
 
 
