@@ -61,6 +61,15 @@ def ctypes_lib():
     if not os.path.exists(LIB_PATH):
         raise UnastHipError("libunast_hip.so not found at %s — build it with `make -C unast_amd/csrc` "
                             "(or python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path." % LIB_PATH)
+    # The library's kernels register with the HIP runtime when it is loaded.  Loading it before the process's runtime (torch's) has
+    # opened the device left them unlaunchable ("no ROCm-capable device is detected": build() followed by smoke() in one process), so the
+    # device is opened first wherever there is one.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in parse_header().items():
         try:
