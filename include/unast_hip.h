@@ -203,8 +203,8 @@ int unast_speech_loss_fwd(const float* gold, const float* head, int ldh, const f
                           float eos_weight, double* ws, float* loss, hipStream_t stream);
 int unast_speech_loss_bwd(const float* gold, const float* head, int ldh, const float* post, const int* lens, int B, int T, int M,
                           float eos_weight, const float* gscale, float* d_head, float* d_post, hipStream_t stream);
-/* text_loss (src/train.py:105-111): weighted CE, ignore_index 0, EOS(2) weight; one launch forward.  ws: 4 doubles -- [0..2] zero on entry and
- * left zero on exit, [3] receives the weight sum the backward of THIS call reads (keep ws untouched until then). */
+/* text_loss (src/train.py:105-111): weighted CE, ignore_index 0, EOS(2) weight; one launch forward.  ws: 5 doubles -- [0..3] zero on entry and
+ * left zero on exit, [4] receives the weight sum the backward of THIS call reads (keep ws untouched until then). */
 int unast_text_loss_fwd(const float* logits, int ldl, const int64_t* gold, int rows, int V, float eos_weight,
                         double* ws, float* loss, hipStream_t stream);
 int unast_text_loss_bwd(const float* logits, int ldl, const int64_t* gold, int rows, int V, float eos_weight, const double* ws,

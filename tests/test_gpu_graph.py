@@ -274,3 +274,33 @@ def test_lru_keeps_the_hot_shape_while_cold_ones_pass_through(monkeypatch):
     assert len(captured) == len(set(captured)), "a capture still cached was made again"
     assert stepper.stats["evictions"] >= 1 and len(stepper.graphs) <= 4 and hot_sig[0] in stepper.graphs, stepper.stats
     assert all(np.isfinite([float(x) for x in v]).all() for v in losses.values())
+
+
+def test_loss_workspace_ring_wraps_without_harm():
+    """Thirty eager steps: the loss kernels' zero-on-entry workspaces come from a 64-slot ring shared by the text and the speech loss, so
+    slots change hands between the two kernels after about ten steps (the text loss's saved weight sum must not be taken for the speech
+    loss's arrival counter); losses stay finite and equal those of a run that gets a fresh zeroed workspace per call."""
+    from unast_amd import train, utils
+    from unast_amd.engine import join_streams
+    out = []
+    for fresh in (False, True):
+        utils.set_deterministic(True)
+        try:
+            args, model, opt, sched = build(2, 1e-4)
+            real = train._loss_ws
+            if fresh:
+                train._loss_ws = lambda dev: torch.zeros(8, dtype=torch.float64, device=dev)
+            losses = defaultdict(list)
+            try:
+                for i in range(30):
+                    train.train_step(losses, model, opt, None, batches_for(i % 3, 3, 20, 48), i, args, defer_d_phase=True)
+            finally:
+                train._loss_ws = real
+            join_streams(); torch.cuda.synchronize()
+            out.append({k: [float(x) for x in v] for k, v in losses.items()})
+        finally:
+            utils.set_deterministic(False)
+    a, b = out
+    for k in a:
+        assert len(a[k]) == 30 and np.isfinite(a[k]).all(), k
+        assert np.allclose(a[k], b[k], rtol=2e-4, atol=1e-6), (k, np.abs(np.array(a[k]) - np.array(b[k])).max())

@@ -290,12 +290,15 @@ def test_losses_match_oracle():
     lr = logits[:, :V].clone().double().view(B, T, V).requires_grad_(True)
     ref = R.text_loss(text, lr, 3.0)
     (ref * 0.25).backward()
-    ws2 = torch.zeros(4, dtype=torch.float64, device=D)
+    ws2 = torch.zeros(8, dtype=torch.float64, device=D)
     for _ in range(2):
         loss.fill_(-1.0)
         ops.text_loss_fwd(logits.to(D), text.to(D).view(-1), V, 3.0, ws2, loss)
         assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
-        assert bool((ws2[:3].view(torch.int64) == 0).all()) and float(ws2[3]) > 0
+        assert bool((ws2[:4].view(torch.int64) == 0).all()) and float(ws2[4]) > 0
+    ops.speech_loss_fwd(gold.to(D), head.to(D), post.to(D), li, 5.0, ws2, loss)          # a slot the text loss has used serves the speech loss
+    assert abs(loss.item() - R.speech_loss(gold.double(), gold_stop, hp.detach(), pp.detach(), lens, st.detach(), 5.0).item()) < 1e-5 * abs(loss.item())
+    ops.text_loss_fwd(logits.to(D), text.to(D).view(-1), V, 3.0, ws2, loss)
     gs = torch.tensor([0.25], device=D); dl = torch.empty(B * T, 48, device=D)
     ops.text_loss_bwd(logits.to(D), text.to(D).view(-1), V, 3.0, ws2, gs, dl)
     assert relerr(dl[:, :V].reshape(B, T, V), lr.grad) < 1e-5 and (dl[:, V:] == 0).all()

@@ -29,4 +29,5 @@ else
   timeout -k 10 200 python tools/bench_kpanel.py > $O/bench_kpanel.txt 2>&1
   timeout -k 10 300 python tools/bench_panel.py > $O/bench_panel.txt 2>&1
   timeout -k 10 200 python tools/bench_attn.py > $O/bench_attn.txt 2>&1
+  timeout -k 10 400 python tools/soak_graph.py > $O/soak_graph.txt 2>&1; tail -1 $O/soak_graph.txt
 fi

@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void speech_loss_bwd_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Text loss: one thread per token (V = 46 logits).  ws doubles: [0] sum w*nll, [1] sum w, [2] workgroups arrived, [3] sum w of the LAST
-// call (what the backward reads).  One launch, as speech_loss_fwd_kernel: zero on entry, [0..2] zero again on exit.
+// Text loss: one thread per token (V = 46 logits).  ws doubles: [0] sum w*nll, [1] sum w, [3] workgroups arrived (the same word as in the
+// speech loss: workspaces are handed out from one ring), [4] sum w of the LAST call (what the backward reads; need not be zero on entry).
+// One launch, as speech_loss_fwd_kernel: [0..3] zero on entry and zero again on exit.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void text_loss_fwd_kernel(const float* __restrict__ logits, int ldl, const int64_t* __restrict__ gold, int rows, int V,
                                                             int eos_idx, float eos_weight, int pad_idx, double* __restrict__ ws, float* __restrict__ loss) {
@@ -125,13 +126,13 @@ __global__ __launch_bounds__(256) void text_loss_fwd_kernel(const float* __restr
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long*>(ws + 2), 1ull) + 1ull;
+        const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long*>(ws + 3), 1ull) + 1ull;
         if (arrived == gridDim.x) {
             __threadfence();
             const double s0 = atomicAdd(ws + 0, 0.0), s1 = atomicAdd(ws + 1, 0.0);
             loss[0] = (float)(s0 / s1);
-            ws[3] = s1;
-            ws[0] = 0.0; ws[1] = 0.0; reinterpret_cast<unsigned long long*>(ws)[2] = 0ull;
+            ws[4] = s1;
+            ws[0] = 0.0; ws[1] = 0.0; reinterpret_cast<unsigned long long*>(ws)[3] = 0ull;
         }
     }
 }
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void text_loss_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void text_loss_bwd_kernel(const float* __restrict__ logits, int ldl, const int64_t* __restrict__ gold, int rows, int V,
                                                             int eos_idx, float eos_weight, int pad_idx, const double* __restrict__ ws,
                                                             const float* __restrict__ gscale, float* __restrict__ dlogits) {
-    const float k = gscale[0] / (float)ws[3];
+    const float k = gscale[0] / (float)ws[4];
     for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
         const int y = (int)gold[r];
         float* dr = dlogits + (size_t)r * ldl;
@@ -218,7 +219,7 @@ extern "C" int unast_speech_loss_bwd(const float* gold, const float* head, int l
 }
 
 extern "C" int unast_text_loss_fwd(const float* logits, int ldl, const int64_t* gold, int rows, int V, float eos_weight,
-                                   double* ws /* 4 doubles: [0..2] zero on entry and on exit, [3] kept for bwd */, float* loss, hipStream_t stream) {
+                                   double* ws /* 5 doubles: [0..3] zero on entry and on exit, [4] kept for bwd */, float* loss, hipStream_t stream) {
     UNAST_REQUIRE(logits && gold && ws && loss && rows > 0 && V > 0 && ldl >= V, "unast_text_loss_fwd: bad arguments");
     hipLaunchKernelGGL(text_loss_fwd_kernel, dim3(ls_grid(rows)), dim3(256), 0, stream, logits, ldl, gold, rows, V, 2, eos_weight, 0, ws, loss);
     return unast_check_launch("unast_text_loss_fwd");

@@ -122,12 +122,18 @@ _WS_RING = {}
 
 
 def _loss_ws(dev):
-    """Four zeroed doubles for one loss call: the loss kernels take their workspace zero and leave it zero (csrc/loss.hip), so the slots of
-    a small ring are handed out round-robin and never filled again; a slot comes back after 64 calls, long after its call's backward (the
-    text loss keeps its weight sum in slot word 3 until then)."""
+    """Eight doubles for one loss call, the first four zero: the loss kernels take their workspace zero and leave it zero (csrc/loss.hip), so
+    the slots of a small ring are handed out round-robin and never filled again; a slot comes back after 64 calls, long after its call's
+    backward (the text loss keeps its weight sum in word 4 until then)."""
     ring = _WS_RING.get(dev)
     if ring is None:
-        ring = _WS_RING[dev] = [torch.zeros(64, 4, dtype=torch.float64, device=dev), 0]
+        # The ring is filled ONCE, on whichever side stream asks first, and then used from all of them: every stream has to be behind that
+        # fill (the text side once read its slot's weight sum as 0 -- wiped by the late fill -- and produced inf gradients: T_text = 300 hit
+        # the window, T_text = 180 did not).  One device-wide synchronisation per process; never inside a capture (the first step is eager).
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the loss workspace ring must exist before a HIP-graph capture (run one eager step first)")
+        ring = _WS_RING[dev] = [torch.zeros(64, 8, dtype=torch.float64, device=dev), 0]
+        torch.cuda.synchronize(dev)
     i = ring[1]
     ring[1] = (i + 1) % 64
     return ring[0][i]
