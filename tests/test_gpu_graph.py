@@ -286,7 +286,7 @@ def test_loss_workspace_ring_wraps_without_harm():
     for fresh in (False, True):
         utils.set_deterministic(True)
         try:
-            args, model, opt, sched = build(2, 1e-4)
+            args, model, opt, sched = build(2, 1e-7)            # frozen parameters: a step's losses depend on its batch only
             real = train._loss_ws
             if fresh:
                 train._loss_ws = lambda dev: torch.zeros(8, dtype=torch.float64, device=dev)
@@ -303,4 +303,4 @@ def test_loss_workspace_ring_wraps_without_harm():
     a, b = out
     for k in a:
         assert len(a[k]) == 30 and np.isfinite(a[k]).all(), k
-        assert np.allclose(a[k], b[k], rtol=2e-4, atol=1e-6), (k, np.abs(np.array(a[k]) - np.array(b[k])).max())
+        assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-6), (k, np.abs(np.array(a[k]) - np.array(b[k])).max())
