@@ -672,6 +672,7 @@ def masked_mse(gold, pred, mask):
     ws = _MSE_WS.get(dev)
     if ws is None:
         ws = _MSE_WS[dev] = torch.zeros(3, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)                  # filled once, used from any stream afterwards: nobody may run ahead of the fill
     out = torch.empty((), dtype=torch.float32, device=dev)
     check(lib().unast_masked_mse(_p(gold), _p(pred), _p(mask), gold.numel(), _p(ws), _p(out), _stream()), "unast_masked_mse")
     return out
