@@ -248,7 +248,7 @@ class _WgradItem(_ct.Structure):          # include/unast_hip.h: unast_wgrad_ite
 
 _BATCH = None            # list of pending (dy2d, x2d, dW, db) while inside `wgrad_batch()`
 GROUP_MAX = 8
-WGRAD_GROUP_TARGET = int(_os.environ.get("UNAST_WGRAD_GROUP_TARGET", "512"))
+WGRAD_GROUP_TARGET = int(_os.environ.get("UNAST_WGRAD_GROUP_TARGET", "256"))      # workgroups per grouped launch: 29.42 vs 29.65 ms/step at 512 (three alternating runs each, same box; round 2 preferred 512 when one stream bounded the step)
 
 
 class wgrad_batch:
