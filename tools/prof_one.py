@@ -32,6 +32,14 @@ elif which in ("panel_ffn1", "tile_ffn1"):
     x = torch.randn(M, K, device=D); W = torch.randn(N, K, device=D) * 0.05; b = torch.randn(N, device=D); y = torch.empty(M, N, device=D)
     pl = Planes([W])
     for _ in range(10):
-        if which == "panel_ffn1": ops.panel_gemm(x, pl.ref(0), y, N, bias=b, act=1, drop_p=0.1, seed=5, stream_id=3, rows_per_wg=128)
-        else: ops.linear_fwd(x, W, b, y, act=1, drop_p=0.1, seed=5, stream_id=3)
+        if which == "panel_ffn1": ops.panel_gemm(x, pl.ref(0), y, N, bias=b, act=1, drop_p=0.1, seed=5, stream_id=3, rows_per_wg=int(os.environ.get("PANEL_ROWS", "1128")))
+        else: ops.gemm(ops.OP_KC, ops.OP_KC, x, K, W, K, y, N, M, N, K, bias=b, act=1, drop_p=0.1, seed=5, stream_id=3)
+elif which == "kpanel_ffn2":
+    from unast_amd.planes import Planes
+    M, N, K = 25600, 256, 1024
+    x = torch.randn(M, K, device=D); W = torch.randn(N, K, device=D) * 0.03; b = torch.randn(N, device=D); z = torch.empty(M, N, device=D); y = torch.empty(M, N, device=D)
+    R = torch.randn(M, N, device=D); gm = torch.rand(N, device=D) + 0.5; bt = torch.randn(N, device=D); mean = torch.empty(M, device=D); rstd = torch.empty(M, device=D)
+    pl = Planes([W])
+    for _ in range(10):
+        ops.panel_gemm(x, pl.ref(0), z, N, bias=b, R=R, drop_p=0.1, seed=9, stream_id=2, ln=(gm, bt, y, mean, rstd, 1e-5))
 torch.cuda.synchronize()
