@@ -573,8 +573,7 @@ extern "C" int unast_retile_weights(const float* src_base, void* dst_base, const
 // ---------------------------------------------------------------------------------------------------------------
 // K-streamed panel (K > 256, N a multiple of 256): the OUTPUT is the stationary operand.  A workgroup of 16 waves owns 128 rows x 256
 // columns; wave (rg, ch) accumulates rows [32 rg, 32 rg + 32) x columns [64 ch, 64 ch + 64) -- two row tiles against four column
-// tiles, so every weight fragment read from LDS feeds 6 MFMAs (the A-stationary kernel above: 3; its 16-wave form is bound by the LDS
-// read port).  K streams in groups of 32 through two three-slot LDS rings filled by LDS-DMA two groups ahead: the weights of a group
+// tiles, so every weight fragment read from LDS feeds 6 MFMAs (the A-stationary kernel above: 3).  K streams in groups of 32 through two three-slot LDS rings filled by LDS-DMA two groups ahead: the weights of a group
 // (256 n x 32 k, both planes = 32 KB, from the same tiled planes) and the activations of a group (128 rows x 32 k of fp32 = 16 KB, whole
 // 128-byte row pieces, 8 rows per DMA instruction; every wave then reads its 32 rows as MFMA fragments and splits them).  One raw
 // s_barrier per group.  (A first version loaded the activation fragments straight into registers: correct, and 1.5x SLOWER than the tile
