@@ -72,11 +72,14 @@ int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* K, int ldk,
                    float drop_p, unsigned int seed, unsigned int stream_id, int qkv_split, hipStream_t stream);
 /* Backward of the above (autograd of the same torch call sites): dQ, dK, dV from dO; delta_ws is [B,H,Tq] scratch.
  * fused = 1: one pass over the (query, key) tiles produces all three (dS crosses LDS for dQ, key blocks are summed into dQ with
- * fp32 atomics, dQ is zeroed first); fused = 0: a dQ kernel and a dK/dV kernel that each recompute the probabilities. */
+ * fp32 atomics, dQ is zeroed first); fused = 0: a dQ kernel and a dK/dV kernel that each recompute the probabilities.
+ * lens_q (may be NULL; fused = 1 only): the caller's guarantee that dO[b, t, :] == 0 for t >= lens_q[b] -- those query tiles are not
+ * visited (their dQ stays zero, they add nothing to dK / dV).  An encoder's self-attention in the train step: nothing downstream of an
+ * encoder reads a padded position, so their gradients are exactly zero (opt-in: unast_amd.config.ENC_SKIP_PAD_GRADS). */
 int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                    const float* dO, int lddo, const float* LSE, float* delta_ws, float* dQ, int lddq, float* dK, int lddk,
                    float* dV, int lddv, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
-                   float drop_p, unsigned int seed, unsigned int stream_id, int fused, int qkv_split, hipStream_t stream);
+                   float drop_p, unsigned int seed, unsigned int stream_id, int fused, int qkv_split, const int* lens_q, hipStream_t stream);
 
 /* LayerNorm(eps) of the post-LN transformer blocks (norm1/2/3 inside torch layers, src/module.py:273-274,286-287).
  * bwd: dz (and optionally dz_drop = dz * dropout mask/(1-p), the gradient of the dropped sub-layer output);

@@ -304,3 +304,30 @@ def test_loss_workspace_ring_wraps_without_harm():
     for k in a:
         assert len(a[k]) == 30 and np.isfinite(a[k]).all(), k
         assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-6), (k, np.abs(np.array(a[k]) - np.array(b[k])).max())
+
+
+def test_encoder_backward_without_padded_query_tiles_gives_the_same_gradients(monkeypatch):
+    """config.ENC_SKIP_PAD_GRADS (opt-in): the backward of the encoders' self-attention stops at each sequence's length.  In the train step
+    every gradient that reaches a padded encoder position is exactly zero, so the generator's gradients must not change (ragged batch)."""
+    from unast_amd import config, train, utils
+    from unast_amd.engine import join_streams
+    grads = []
+    utils.set_deterministic(True)
+    try:
+        for flag in (False, True):
+            monkeypatch.setattr(config, "ENC_SKIP_PAD_GRADS", flag)
+            args, model, opt, sched = build(2, 1e-7)
+            losses = defaultdict(list)
+            b = batches_for(5, 4, 28, 96)
+            train.freeze_model_parameters(model.discriminator)
+            train.train_ae_step(losses, model, b["unsup"][0], 0, 2, args)
+            train.train_sp_step(losses, model, b["sup"][0], 0, 2, args)
+            join_streams(); torch.cuda.synchronize()
+            st = model._store()
+            a, e = st.regions["gen"]
+            grads.append(st.grad[a:e].clone())
+    finally:
+        utils.set_deterministic(False)
+    g0, g1 = grads
+    assert bool(torch.isfinite(g0).all()) and float(g0.abs().max()) > 0
+    assert float((g0 - g1).abs().max()) <= 2e-6 * float(g0.abs().max()), float((g0 - g1).abs().max())

@@ -87,3 +87,8 @@ PANEL_GATE_BITS = os.environ.get("UNAST_PANEL_GATE_BITS", "1") != "0"
 # torch.distributed calls: stream-ordered, one ctypes call per bucket, and -- because the stream-replay executor can issue it from C++ --
 # the captured train step stays usable under a process group.  0 = torch.distributed all_reduce (eager step only).
 NATIVE_COMM = os.environ.get("UNAST_NATIVE_COMM", "1") != "0"
+
+# Opt-in (default off): the backward of an ENCODER's self-attention does not visit query tiles past the sequence length.  Exact in the
+# train step -- nothing downstream of an encoder reads a padded position (cross-attention and the discriminator mask by length), so dO is
+# zero there -- but not for a caller who puts a loss on padded encoder outputs, which the reference would differentiate.
+ENC_SKIP_PAD_GRADS = os.environ.get("UNAST_ENC_SKIP_PAD_GRADS", "0") == "1"

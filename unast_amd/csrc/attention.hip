@@ -35,6 +35,7 @@ struct AttnParams {
     const float* Delta;                // [B,H,Tq]  bwd
     float* dK; float* dV; int lddk, lddv;
     const int* lens_k;
+    const int* lens_q;                 // bwd, optional: queries t >= lens_q[b] carry a zero dO (the caller's guarantee): their tiles are not visited
     int B, H, Tq, Tk, causal;
     float scale;
     uint32_t drop_thresh; float drop_scale; uint32_t seed, stream;
@@ -446,7 +447,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
     const uint32_t rbase = rng_stream_base(p.seed, p.stream);      // rng_row_key(seed, stream, row) = pcg(row + rbase)
     const bool block_live = kblk < klen;                    // all keys of the block masked -> gradients are zero
     const int qt_begin = p.causal ? (kblk / 32) : 0;
-    const int qt_end = block_live ? (p.Tq + 31) / 32 : qt_begin;
+    const int qlen = p.lens_q ? min(p.Tq, max(p.lens_q[b], 0)) : p.Tq;
+    const int qt_end = block_live ? (qlen + 31) / 32 : qt_begin;
     float4 rq[2], rd[2];
     // Softmax statistics of the query tile: lane L of every wave prefetches LSE (lanes 0-31) or Delta (lanes 32-63) of query
     // L & 31 together with the Q / dO tile; the pointwise phase fetches its 2 x 4 rows with lane shuffles instead of eight
@@ -667,6 +669,7 @@ static int fill_common(AttnParams& p, const float* Q, int ldq, const float* K, i
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.causal = causal; p.scale = scale;
     p.drop_thresh = drop_threshold(drop_p); p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.seed = seed; p.stream = stream_id;
     p.qkv_split = qkv_split;
+    p.lens_q = nullptr;
     p.O = nullptr; p.LSE = nullptr; p.dO = nullptr; p.Delta = nullptr; p.dK = nullptr; p.dV = nullptr; p.ldo = p.lddo = p.lddk = p.lddv = 0;
     return UNAST_OK;
 }
@@ -692,11 +695,13 @@ extern "C" int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* 
 extern "C" int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                               const float* dO, int lddo, const float* LSE, float* delta_ws, float* dQ, int lddq, float* dK, int lddk,
                               float* dV, int lddv, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
-                              float drop_p, unsigned int seed, unsigned int stream_id, int fused, int qkv_split, hipStream_t stream) {
+                              float drop_p, unsigned int seed, unsigned int stream_id, int fused, int qkv_split, const int* lens_q, hipStream_t stream) {
     AttnParams p;
     int rc = fill_common(p, Q, ldq, K, ldk, V, ldv, lens_k, B, H, Tq, Tk, head_dim, causal, scale, drop_p, seed, stream_id, qkv_split);
     if (rc) return rc;
     UNAST_REQUIRE(O && dO && LSE && delta_ws && dQ && dK && dV, "unast_attn_bwd: null pointer");
+    UNAST_REQUIRE(!lens_q || fused, "unast_attn_bwd: lens_q is served by the one-pass backward (fused = 1)");
+    p.lens_q = lens_q;
     UNAST_REQUIRE(al16(O) && al16(dO) && al16(dQ) && al16(dK) && al16(dV) && ((ldo | lddo | lddq | lddk | lddv) & 3) == 0,
                   "unast_attn_bwd: operands must be 16-byte aligned with ld%%4==0");
     UNAST_REQUIRE(nsplit == 1 || nsplit == 3, "unast_attn_bwd: nsplit must be 1 or 3");

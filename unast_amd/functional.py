@@ -61,7 +61,7 @@ def _layernorm(cx, tape, z, pre, x_res_grad_sink):
     return y, mean, rstd
 
 
-def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, Tk, H, drop):
+def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, Tk, H, drop, pad_free_grads=False):
     """y = LN(x + dropout(MHA(x, mem or x)))  with attention-probability dropout `drop` as well.
     x: Var [B*Tq, E]; mem: Var [B*Tk, E] or None for self-attention."""
     E = x.v.shape[1]
@@ -117,7 +117,7 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
             if mem is None:
                 dqkv = _empty(Nq, 3 * E, like=z)
                 ops.attn_bwd(Q, K, V, O, dO, LSE, delta, dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:], lens_k, B, H, Tq, Tk, causal,
-                             drop_p=p, seed=seed, stream_id=s_attn, qkv_split=ps)
+                             drop_p=p, seed=seed, stream_id=s_attn, qkv_split=ps, lens_q=lens_k if (pad_free_grads and config.ENC_SKIP_PAD_GRADS) else None)
                 if gW is not None:
                     ops.linear_wgrad(dqkv, x.v, gW, db=gb)
                 dx = _empty(Nq, E, like=z)
@@ -196,7 +196,7 @@ def encoder_stack(cx, tape, x, lens, pre, L, B, T, H, drop):
     """src/module.py:270-280 (TransformerEncoder): all-False attn mask + key padding mask."""
     for i in range(L):
         lp = "%s%d." % (pre, i)
-        x = attn_sublayer(cx, tape, x, None, lens, False, lp + "self_attn.", lp + "norm1.", B, T, T, H, drop)
+        x = attn_sublayer(cx, tape, x, None, lens, False, lp + "self_attn.", lp + "norm1.", B, T, T, H, drop, pad_free_grads=True)
         x = ffn_sublayer(cx, tape, x, lp, lp + "norm2.", drop)
     return x
 

@@ -416,11 +416,12 @@ def attn_fwd(Q, K, V, O, LSE, lens_k, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, 
                                int(qkv_split), _stream()), "unast_attn_fwd")
 
 
-def attn_bwd(Q, K, V, O, dO, LSE, delta_ws, dQ, dK, dV, lens_k, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, stream_id=0, nsplit=None, qkv_split=False):
+def attn_bwd(Q, K, V, O, dO, LSE, delta_ws, dQ, dK, dV, lens_k, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, stream_id=0, nsplit=None, qkv_split=False, lens_q=None):
+    """lens_q (int32 [B], one-pass backward only): queries t >= lens_q[b] have a zero dO by the caller's guarantee; their tiles are skipped."""
     check(lib().unast_attn_bwd(nsplit or config.NSPLIT, _p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0),
                                _p(dO), dO.stride(0), _p(LSE), _p(delta_ws), _p(dQ), dQ.stride(0), _p(dK), dK.stride(0), _p(dV),
                                dV.stride(0), _p(lens_k), B, H, Tq, Tk, 64, int(causal), 0.125, drop_p, seed & 0xFFFFFFFF, stream_id,
-                               int(config.ATTN_FUSED_BWD), int(qkv_split), _stream()), "unast_attn_bwd")
+                               int(config.ATTN_FUSED_BWD), int(qkv_split), _p(lens_q) if config.ATTN_FUSED_BWD else None, _stream()), "unast_attn_bwd")
 
 
 # ---- normalisation -----------------------------------------------------------------------------------------
