@@ -180,6 +180,9 @@ int unast_decode_end_speech(const float* head, int ld, int M, int B, float* outp
                             int64_t max_len, int64_t* pos, int* epoch, hipStream_t stream);
 /* a *= alpha: averaging of all-reduced gradients across data-parallel ranks (new vs. the single-device reference). */
 int unast_scale_inplace(float* a, float alpha, int64_t n, hipStream_t stream);
+/* Test infrastructure: keeps `stream` busy for `us` microseconds (one spinning wave).  unast_amd.config.STREAM_JITTER puts one of random
+ * length at the head of every side-stream call to flush out missing cross-stream dependencies (tests/test_gpu_streams.py). */
+int unast_spin(int us, hipStream_t stream);
 /* Teacher-forced decoder input (src/network.py:254-262): dst[b,0,:] = 0, dst[b,t,:] = src[b,t-1,:] for [B,T,M] fp32 (M % 4 == 0). */
 int unast_shift_frames(const float* src, float* dst, int B, int T, int M, hipStream_t stream);
 /* dst[:, :cols] += src[:, :cols] with independent row strides (autograd's add for padded gradient buffers). */

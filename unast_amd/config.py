@@ -92,3 +92,8 @@ NATIVE_COMM = os.environ.get("UNAST_NATIVE_COMM", "1") != "0"
 # train step -- nothing downstream of an encoder reads a padded position (cross-attention and the discriminator mask by length), so dO is
 # zero there -- but not for a caller who puts a loss on padded encoder outputs, which the reference would differentiate.
 ENC_SKIP_PAD_GRADS = os.environ.get("UNAST_ENC_SKIP_PAD_GRADS", "0") == "1"
+
+# Test infrastructure: > 0 = every side-stream call (forward, backward segment, weight-gradient companion) starts with a spin kernel of
+# random length up to this many microseconds, which shifts the streams against each other; results must not change (tests/test_gpu_streams.py).
+STREAM_JITTER = int(os.environ.get("UNAST_STREAM_JITTER", "0"))
+STREAM_JITTER_SEED = int(os.environ.get("UNAST_STREAM_JITTER_SEED", "0"))

@@ -373,6 +373,21 @@ extern "C" int unast_shift_frames(const float* src, float* dst, int B, int T, in
     return unast_check_launch("unast_shift_frames");
 }
 
+// Test infrastructure (unast_amd.config.STREAM_JITTER): one wave that keeps its stream busy for `us` microseconds of the constant
+// 100 MHz clock.  Placed at the head of every side-stream call it shifts the streams against each other, so a missing dependency
+// (a buffer filled on one stream and read on another without an event in between) changes results instead of hiding behind timing.
+__global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) { __builtin_amdgcn_s_sleep(32); }
+}
+
+extern "C" int unast_spin(int us, hipStream_t stream) {
+    UNAST_REQUIRE(us >= 0 && us <= 100000, "unast_spin: 0..100 000 us");
+    if (us == 0) return UNAST_OK;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long)us * 100ull);
+    return unast_check_launch("unast_spin");
+}
+
 extern "C" int unast_add_strided(float* dst, int ldd, const float* src, int lds, int rows, int cols, hipStream_t stream) {
     UNAST_REQUIRE(dst && src && rows > 0 && cols > 0 && ldd >= cols && lds >= cols, "unast_add_strided: bad arguments");
     hipLaunchKernelGGL(add_strided_kernel, dim3(ew_grid((size_t)rows * cols)), dim3(256), 0, stream, dst, ldd, src, lds, rows, cols);

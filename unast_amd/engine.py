@@ -184,6 +184,7 @@ def on_stream(name):
                 kw = {k: route(v) for k, v in kw.items()}
             s.wait_stream(cur)
             with torch.cuda.stream(s):
+                ops.jitter()                            # (test infrastructure, off by default: config.STREAM_JITTER)
                 if _Streams.trace is not None:          # diagnostic only (tools/stream_timeline.py): event pair around the call
                     import time
                     e0 = torch.cuda.Event(enable_timing=True); e0.record(); h0 = time.perf_counter()
@@ -255,6 +256,7 @@ class _Segment(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        ops.jitter()                                    # (test infrastructure, off by default: config.STREAM_JITTER)
         if _Streams.trace is not None:                  # diagnostic only (tools/stream_timeline.py)
             import time
             e0 = torch.cuda.Event(enable_timing=True); e0.record()

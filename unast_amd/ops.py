@@ -226,6 +226,7 @@ def _on_wgrad_stream(launch, tokens, key, *operands):
         if t is not None:
             t.record_stream(w)
     with torch.cuda.stream(w):
+        jitter()
         return launch()
 
 
@@ -571,6 +572,20 @@ def decode_end_speech(head, M, outputs, stops, stop_lens, max_len, pos, epoch):
 
 def scale_inplace(a, alpha):
     check(lib().unast_scale_inplace(_p(a), float(alpha), a.numel(), _stream()), "unast_scale_inplace")
+
+
+_JITTER = [0]
+
+
+def jitter():
+    """config.STREAM_JITTER > 0: a spin of pseudo-random length (0 .. STREAM_JITTER us, a third of the calls none) on the current stream."""
+    if not config.STREAM_JITTER:
+        return
+    _JITTER[0] = (_JITTER[0] * 1103515245 + 12345 + config.STREAM_JITTER_SEED) & 0x7FFFFFFF
+    r = (_JITTER[0] >> 8) % 3000
+    if r >= 2000:
+        return
+    check(lib().unast_spin(int(r * config.STREAM_JITTER / 2000), _stream()), "unast_spin")
 
 
 def shift_frames(mel3d, out3d):
