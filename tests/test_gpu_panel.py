@@ -217,3 +217,12 @@ def test_train_step_with_and_without_the_panel_kernel_agree():
             assert abs(a - b) <= (2e-4 if i == 0 else 2e-3) * max(1.0, abs(a)), (k, i, a, b)
     d = (res["tile"][1] - res["panel"][1]).abs()
     assert float((d > 1e-5).float().mean()) < 0.06 and float(d.max()) <= 4.1e-3, (float((d > 1e-5).float().mean()), float(d.max()))
+
+
+def test_random_shapes_and_epilogues_both_forms():
+    """tools/fuzz_panel.py: 80 random (M, N, K, epilogue, rows-per-workgroup) cases through the activation-stationary and the K-streamed form
+    against the tile GEMM, bit for bit (LayerNorm epilogue to fp32 rounding), guard rows and columns untouched; in a fresh process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_panel.py"), "80", "5"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0 and b"fuzz panel ok" in out.stdout, out.stdout.decode()[-2000:]
