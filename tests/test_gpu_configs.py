@@ -48,7 +48,7 @@ def build(L, lr, use_discriminator=True):
 # ---------------------------------------------------------------------------------------------------------------
 # config 2: three layers, no discriminator
 # ---------------------------------------------------------------------------------------------------------------
-def test_config2_generator_only_step_matches_reference_golden(golden_dir):
+def test_config2_generator_only_step_matches_reference_golden(golden_dir, panel_rows):
     """num_layers=3, use_discriminator=False against the fixture the reference itself produced (tools/gen_golden.py
     step_b3_t20_m56_l3_nodisc): outputs within 1e-3, the four losses, every gradient norm, clip + AdamW deltas."""
     from unast_amd import train
@@ -110,7 +110,7 @@ def test_config2_generator_only_step_matches_reference_golden(golden_dir):
             assert np.abs(sdn[key[3:]].cpu().numpy() - g[key]).max() < 2e-4 * np.abs(g[key]).max() + 1.0 * lr, key
 
 
-def test_config2_full_length_generator_only_vs_oracle_b2():
+def test_config2_full_length_generator_only_vs_oracle_b2(panel_rows):
     """Config 2's sequence lengths (T_text=128, T_mel=512) and depth (L=3) with B=2, generator-only: the train_step surface
     (AE + SP + clip/AdamW, no D phase) against the pinned oracle."""
     from oracle import unast_ref as R

@@ -249,8 +249,9 @@ def test_full_batch_step_is_reproducible_and_finite():
 
 
 def test_config5_full_batch_step_is_reproducible_and_finite():
-    """BASELINE.json config 5 as a step, not only per kernel: B=32, T_mel=2000 (64 000 rows per speech GEMM, 2000x2000 causal
-    attention, 2000-step recurrences), the complete step twice from the same state and seed."""
+    """BASELINE.json config 5 as a step, not only per kernel: B=32, T_text=300, T_mel=2000 (64 000 rows per speech GEMM, 9 600 per
+    text GEMM, 2000x2000 causal attention, 2000x300 / 300x2000 cross-attention, 2000-step recurrences), the complete step twice
+    from the same state and seed."""
     from collections import defaultdict
     from unast_amd import train, utils
     from unast_amd.portable import synth_batch
@@ -260,7 +261,7 @@ def test_config5_full_batch_step_is_reproducible_and_finite():
         utils.set_deterministic(False)
         try:
             utils.set_seed(5)
-            batch = tuple(torch.from_numpy(x) for x in synth_batch(B, TT, 2000, seed=2, ragged=True))
+            batch = tuple(torch.from_numpy(x) for x in synth_batch(B, 300, 2000, seed=2, ragged=True))
             batches = dict(unsup=[batch], sup=[batch], disc=[batch], cm=[])
             losses = defaultdict(list)
             train.train_step(losses, model, opt, None, batches, 1, args)
@@ -312,3 +313,41 @@ def test_deferred_discriminator_phase_matches_joined():
     # that tolerance is meaningful: the deliberately stale run differs by clearly more in the D-dependent losses of the step after
     stale_gap = max(abs(a - b) / max(1.0, abs(a)) for k in ("d", "d_ae", "sp_d") for a, b in zip(res[0][k][3:], res[2][k][3:]))
     assert stale_gap > 3 * max(gap, 1e-4), (stale_gap, gap)
+
+
+def test_replayed_soak_over_two_ragged_shapes_stays_finite_and_learns():
+    """The run that caught the loss-workspace race of round 3 (NaN parameters at B=32 / T_text=300 / T_mel=2000 while
+    every other test was green), inside the suite: replayed steps (capture at the second meeting of a shape, csrc/graph_exec.cpp
+    afterwards) alternating between config 5's shape and a B=16 / 180 / 800 one, ragged lengths, random sites on.  Parameters
+    and losses stay finite and the speech auto-encoder loss falls (reference step: /root/reference/src/train.py:199-259, 358-363)."""
+    from collections import defaultdict
+    from unast_amd import train, utils
+    from unast_amd.configs import make_args
+    from unast_amd.graphed import GraphedTrainStep
+    from unast_amd.portable import synth_batch
+    train.DEVICE = D
+    args = make_args(num_layers=4, ae_steps=1, sp_steps=1, d_steps=1, cm_steps=0, warmup_steps=200)      # lr reaches 2e-4 by step 10
+    utils.set_seed(0)
+    utils.set_deterministic(False)
+    try:
+        _, _, model, opt, sched = train.initialize_model(args)
+        stepper = GraphedTrainStep(model, opt, sched, args)
+        losses = defaultdict(list)
+        shapes = ((32, 300, 2000), (16, 180, 800))
+        data = {s: [tuple(torch.from_numpy(x).to(D) for x in synth_batch(*s, seed=k, ragged=True)) for k in range(2)] for s in shapes}
+        for i in range(14):
+            s = shapes[(i // 3) % 2]             # three steps of one shape, then three of the other: eager, captured, replayed ... and back
+            batch = data[s][i % 2]
+            stepper(losses, dict(unsup=[batch], sup=[batch], disc=[batch], cm=[]), i)
+        stepper.flush(losses)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(model._store().flat).all()), "non-finite parameters after the soak"
+        for k, v in losses.items():
+            vals = [float(x) for x in v]
+            assert all(x == x and abs(x) < 1e4 for x in vals), (k, vals)
+        s_ae = [float(x) for x in losses["s_ae"]]
+        assert len(s_ae) == 14
+        assert s_ae[12] < s_ae[0] and s_ae[10] < s_ae[4], s_ae          # the same batch of either shape, 12 / 6 updates later
+        assert stepper.stats["replays"] >= 4, stepper.stats
+    finally:
+        utils.set_deterministic(True)

@@ -43,7 +43,7 @@ def load_case(golden_dir, name):
 
 
 @pytest.mark.parametrize("name", ["step_b1_t40_m200_l4", "step_b4_t24_m64_l2", "step_b4_t24_m64_l4_lr0"])
-def test_forward_matches_reference_golden(golden_dir, name):
+def test_forward_matches_reference_golden(golden_dir, name, panel_rows):
     from unast_amd import train
     g, batch = load_case(golden_dir, name)
     B, Tt, Tm, L, _ = [int(v) for v in g["meta"]]
@@ -68,7 +68,7 @@ def test_forward_matches_reference_golden(golden_dir, name):
 
 
 @pytest.mark.parametrize("name", ["step_b1_t40_m200_l4", "step_b4_t24_m64_l2", "step_b4_t24_m64_l4_lr0"])
-def test_full_step_matches_reference_golden(golden_dir, name):
+def test_full_step_matches_reference_golden(golden_dir, name, panel_rows):
     from collections import defaultdict
     from unast_amd import train
     g, batch = load_case(golden_dir, name)
@@ -132,7 +132,7 @@ def test_full_step_matches_reference_golden(golden_dir, name):
         assert np.allclose(dd[well], tot_d[well], rtol=3e-2, atol=1e-7)
 
 
-def test_ragged_batch_vs_oracle_b8():
+def test_ragged_batch_vs_oracle_b8(panel_rows):
     """A size with no golden fixture (B=8, Tt=70, Tm=300, ragged): forward + losses + gradients vs the pinned oracle."""
     from collections import defaultdict
     from oracle import unast_ref as R

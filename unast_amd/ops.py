@@ -357,6 +357,9 @@ def retile_weights(src_flat, dst_bytes, descs_dev, ndesc):
     check(lib().unast_retile_weights(_p(src_flat), _p(dst_bytes), _p(descs_dev), ndesc, _stream()), "unast_retile_weights")
 
 
+PANEL_LAUNCHES = [0, 0]          # (activation-stationary, K-streamed) launches so far: tests assert which kernel served them
+
+
 def panel_gemm(A, wplanes, C, N, bias=None, R=None, G=None, gate_scale=1.0, act=0, drop_p=0.0, seed=0, stream_id=0, out_split=False,
                ln=None, rows_per_wg=0, K=None, gate_bits=None):
     """C[M,N] = epi(A[M,K] W[N,K]^T) with W given as tiled planes `wplanes` = (hi-plane pointer, plane bytes).
@@ -368,6 +371,7 @@ def panel_gemm(A, wplanes, C, N, bias=None, R=None, G=None, gate_scale=1.0, act=
     if ln is not None:
         g, b, Y, mean, rstd, eps = ln
         ldy = Y.stride(0)
+    PANEL_LAUNCHES[0 if K <= 256 else 1] += 1
     if _PANEL_TRACE:
         print("panel_gemm M=%d N=%d K=%d lda=%d ldc=%d bias=%s R=%s G=%s act=%d drop=%.2f split=%d ln=%s bits=%s rows=%d" % (
             M, N, K, A.stride(0), C.stride(0), bias is not None, R is not None, G is not None, act, drop_p, out_split, ln is not None,
