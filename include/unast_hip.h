@@ -70,9 +70,14 @@ int unast_gemm(int a_mode, int b_mode, int nsplit,
 int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                    float* LSE, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
                    float drop_p, unsigned int seed, unsigned int stream_id, int qkv_split, hipStream_t stream);
+/* Forward kernel choice: 1 = 32x32x16 MFMA tiles (default), 0 = 16x16x32 tiles; m32 < 0 only queries.  Returns the previous value.
+ * Both compute the call above (same masks, same dropout decisions, same three-term products); tests compare them. */
+int unast_attn_fwd_variant(int m32);
 /* Backward of the above (autograd of the same torch call sites): dQ, dK, dV from dO; delta_ws is [B,H,Tq] scratch.
  * fused = 1: one pass over the (query, key) tiles produces all three (dS crosses LDS for dQ, key blocks are summed into dQ with
- * fp32 atomics, dQ is zeroed first); fused = 0: a dQ kernel and a dK/dV kernel that each recompute the probabilities.
+ * fp32 atomics, dQ is zeroed first); fused = 0: a dQ kernel and a dK/dV kernel that each recompute the probabilities;
+ * fused = 2: the one-pass form with the kernel-made operands P and dS as ONE bf16 part in the dV, dK and dQ products (two MFMAs per
+ * product instead of three; ~2e-3 of the largest element on the three gradients instead of ~2e-5: a fast mode, not the default).
  * lens_q (may be NULL; fused = 1 only): the caller's guarantee that dO[b, t, :] == 0 for t >= lens_q[b] -- those query tiles are not
  * visited (their dQ stays zero, they add nothing to dK / dV).  An encoder's self-attention in the train step: nothing downstream of an
  * encoder reads a padded position, so their gradients are exactly zero (opt-in: unast_amd.config.ENC_SKIP_PAD_GRADS). */

@@ -29,10 +29,19 @@ def naive_attention(q, k, v, lens_k, causal, H):
     return (p @ vh).transpose(1, 2).reshape(B, Tq, E), torch.logsumexp(s, -1)
 
 
+@pytest.fixture(params=[1, 0], ids=["mfma32x32", "mfma16x16"])
+def fwd_variant(request):
+    """Both forward kernels (csrc/attention.hip: attn_fwd32_kernel, the default, and attn_q_kernel) serve the same call."""
+    from unast_amd._lib import lib
+    old = lib().unast_attn_fwd_variant(request.param)
+    yield request.param
+    lib().unast_attn_fwd_variant(old)
+
+
 @pytest.mark.parametrize("nsplit", [3, 1])
 @pytest.mark.parametrize("B,Tq,Tk,causal", [(2, 40, 40, False), (3, 200, 200, True), (2, 150, 37, False), (2, 33, 190, False),
                                             (1, 257, 257, True), (2, 128, 64, False)])
-def test_attention_fwd_bwd(nsplit, B, Tq, Tk, causal):
+def test_attention_fwd_bwd(nsplit, B, Tq, Tk, causal, fwd_variant):
     from unast_amd import ops
     H, E = 4, 256
     g = torch.Generator().manual_seed(B * 1000 + Tq + Tk)
@@ -64,6 +73,57 @@ def test_attention_fwd_bwd(nsplit, B, Tq, Tk, causal):
     assert relerr(dQ.view(B, Tq, E), q.grad) < tol
     assert relerr(dKV[:, :E].reshape(B, Tk, E), k.grad) < tol
     assert relerr(dKV[:, E:].reshape(B, Tk, E), v.grad) < tol
+
+
+@pytest.mark.parametrize("B,Tq,Tk,causal,p", [(2, 200, 200, True, 0.0), (3, 150, 37, False, 0.1), (2, 300, 300, False, 0.1), (1, 257, 257, True, 0.1)])
+def test_attention_forward_kernels_agree(B, Tq, Tk, causal, p):
+    """attn_fwd32_kernel (32x32x16 MFMAs, running maximum raised only when it grows by more than 8) against attn_q_kernel (16x16x32)
+    on the same call: same masks and, with dropout on, the SAME keep decisions (an element dropped by one and kept by the other would
+    show as a difference of its whole probability), results equal to accumulation order."""
+    from unast_amd import ops
+    from unast_amd._lib import lib
+    H, E = 4, 256
+    g = torch.Generator().manual_seed(B * 31 + Tq + Tk)
+    q = (torch.randn(B * Tq, E, generator=g) * 2).to(D); k = (torch.randn(B * Tk, E, generator=g) * 2).to(D); v = torch.randn(B * Tk, E, generator=g).to(D)
+    lens = torch.randint(max(1, Tk // 2), Tk + 1, (B,), generator=g).to(torch.int32).to(D)
+    res = []
+    old = lib().unast_attn_fwd_variant(-1)
+    try:
+        for m32 in (0, 1):
+            lib().unast_attn_fwd_variant(m32)
+            o = torch.full((B * Tq, E), float("nan"), device=D); lse = torch.full((B, H, Tq), float("nan"), device=D)
+            ops.attn_fwd(q, k, v, o, lse, lens, B, H, Tq, Tk, causal, drop_p=p, seed=5, stream_id=9)
+            res.append((o, lse))
+    finally:
+        lib().unast_attn_fwd_variant(old)
+    assert relerr(res[1][0], res[0][0].cpu()) < 2e-5 and relerr(res[1][1], res[0][1].cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("B,Tq,Tk,causal", [(2, 40, 40, False), (3, 200, 200, True), (2, 150, 37, False)])
+def test_attention_backward_two_term_mode_stays_within_its_bound(B, Tq, Tk, causal, monkeypatch):
+    """config.ATTN_BWD_TERMS = 2 (opt-in): P and dS as one bf16 part in the dV / dK / dQ products.  One call's gradients are then
+    accurate to the bf16 rounding of P / dS -- bounded here at 4e-3 of the largest element and 3e-3 in norm -- where the default
+    three-term form holds 5e-5 (test_attention_fwd_bwd)."""
+    from unast_amd import ops, config
+    monkeypatch.setattr(config, "ATTN_BWD_TERMS", 2)
+    H, E = 4, 256
+    g = torch.Generator().manual_seed(B * 1000 + Tq + Tk)
+    qkv = torch.randn(B, Tq, 3 * E, generator=g, dtype=torch.float64)
+    kvsrc = qkv if Tq == Tk else torch.randn(B, Tk, 3 * E, generator=g, dtype=torch.float64)
+    lens = torch.randint(max(1, Tk // 2), Tk + 1, (B,), generator=g)
+    lens[0] = Tk
+    q = qkv[..., :E].clone().requires_grad_(True); k = kvsrc[..., E:2 * E].clone().requires_grad_(True); v = kvsrc[..., 2 * E:].clone().requires_grad_(True)
+    o_ref, _ = naive_attention(q, k, v, lens, causal, H)
+    do = torch.randn(B, Tq, E, generator=g, dtype=torch.float64)
+    o_ref.backward(do)
+    qd = qkv.float().to(D).view(B * Tq, 3 * E); kd = kvsrc.float().to(D).view(B * Tk, 3 * E)
+    O = torch.empty(B * Tq, E, device=D); LSE = torch.empty(B, H, Tq, device=D); lens_d = lens.to(torch.int32).to(D)
+    ops.attn_fwd(qd[:, :E], kd[:, E:2 * E], kd[:, 2 * E:], O, LSE, lens_d, B, H, Tq, Tk, causal)
+    dQ = torch.empty(B * Tq, E, device=D); dKV = torch.empty(B * Tk, 2 * E, device=D); ws = torch.empty(B, H, Tq, device=D)
+    ops.attn_bwd(qd[:, :E], kd[:, E:2 * E], kd[:, 2 * E:], O, do.float().to(D).view(B * Tq, E), LSE, ws, dQ, dKV[:, :E], dKV[:, E:], lens_d, B, H, Tq, Tk, causal)
+    for got, ref in ((dQ.view(B, Tq, E), q.grad), (dKV[:, :E].reshape(B, Tk, E), k.grad), (dKV[:, E:].reshape(B, Tk, E), v.grad)):
+        assert relerr(got, ref) < 4e-3
+        assert ((got.double().cpu() - ref).norm() / ref.norm()).item() < 3e-3
 
 
 @pytest.mark.parametrize("B,Tq,Tk,causal,p", [(2, 200, 200, True, 0.0), (3, 150, 37, False, 0.1), (2, 33, 300, False, 0.1), (2, 257, 257, True, 0.1), (1, 5, 5, False, 0.0)])

@@ -51,6 +51,12 @@ WGRAD_GROUP = os.environ.get("UNAST_WGRAD_GROUP", "1") != "0"
 
 # Attention backward as ONE pass (dK, dV and dQ; csrc/attention.hip attn_dkv_kernel<*,1>) instead of a dQ kernel + a dK/dV kernel.
 ATTN_FUSED_BWD = os.environ.get("UNAST_ATTN_FUSED_BWD", "1") != "0"
+# Terms per dV / dK / dQ product of the one-pass backward: 3 = a_hi b_hi + a_hi b_lo + a_lo b_hi as everywhere else; 2 = the probabilities P
+# and the score gradients dS (made by the kernel itself) enter as ONE bf16 part: 12 instead of 15 MFMAs per tile product and no low-part
+# split of P / dS.  tools/oracle_emu_attn_terms.py prices it at the model level (gradient norms and the median gradient error against
+# fp64 do not move: the per-element 2^-9 is zero-mean and a weight gradient sums 25 600 rows), but a single attention call's dQ / dK / dV
+# move from ~2e-5 to ~2e-3 of their largest element, which tests/test_gpu_kernels.py::test_attention_fwd_bwd holds at 5e-5: opt-in.
+ATTN_BWD_TERMS = int(os.environ.get("UNAST_ATTN_BWD_TERMS", "3"))
 
 # Input-gradient GEMMs (dX = dY W) can read W^T from a transposed pre-split copy (K-contiguous operand, as the forward GEMMs read
 # W) instead of the untransposed weights through transposed LDS reads.  Measured on MI355X at config 3: GEMM family 24.08 vs

@@ -106,6 +106,19 @@ __device__ __forceinline__ f32x4 mma3(const bf16x8_t& ah, const bf16x8_t& al, co
     return mfma16(ah, bh, c);
 }
 
+// Products with one operand made by the kernel itself (P, dS) in ONE bf16 part: that operand's low part is left out, i.e. two MFMAs.
+// mma2_a: A = a_hi only (a_hi*b_lo + a_hi*b_hi); mma2_b: B = b_hi only (a_lo*b_hi + a_hi*b_hi).
+template <int NSPLIT>
+__device__ __forceinline__ f32x4 mma2_a(const bf16x8_t& ah, const bf16x8_t& bh, const bf16x8_t& bl, f32x4 c) {
+    if (NSPLIT == 3) c = mfma16(ah, bl, c);
+    return mfma16(ah, bh, c);
+}
+template <int NSPLIT>
+__device__ __forceinline__ f32x4 mma2_b(const bf16x8_t& ah, const bf16x8_t& al, const bf16x8_t& bh, f32x4 c) {
+    if (NSPLIT == 3) c = mfma16(al, bh, c);
+    return mfma16(ah, bh, c);
+}
+
 // global [rows x 64] fp32 tile -> registers (NF float4 per thread); rows >= rows_valid read as zero
 template <int NROWS, int NT = 256>
 __device__ __forceinline__ void tile_load(const float* __restrict__ src, int ld, int rows_valid, float4 (&r)[NROWS * 16 / NT], int t) {
@@ -376,6 +389,230 @@ __global__ __launch_bounds__(128 * (4 / QS), (QS == 1 ? 4 : 2)) void attn_q_kern
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Forward on v_mfma_f32_32x32x16_bf16 (round 4).  Same work split as attn_q_kernel<*, 0, 2> -- 128 queries per workgroup, wave w owns
+// queries [128 bx + 32 w, +32), 64-key tiles through LDS -- but one 32-query x 32-key accumulator tile per MFMA: the instruction holds
+// the SIMD's vector issue for 8 of its 32 cycles instead of 8 of 16 (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'), so the
+// softmax's vector instructions have three times the room under the matrix pipe, and every K fragment read from LDS feeds 32 queries.
+// Layout (C/D of 32x32x16: column n = lane & 31, row = 8 (i / 4) + 4 (lane >> 5) + i % 4 for register i): S^T[key, q] = K.Q^T puts the
+// QUERY on the lane, a lane holds 16 of the 32 keys of a tile and its partner lane ^ 32 the other 16: the row maximum is 15 v_max3 +
+// one permlane32 swap, the row sum stays a per-lane partial until the epilogue.  Registers 8v .. 8v+7 of a tile are the B operand of
+// O^T += V^T.P^T for keys [16 v, 16 v + 16) in the k-slot order 8 (j / 4) + 4 hi + j % 4, which two ds_read_b64_tr_b16 of the untransposed
+// [key][d] image of V deliver.  The running maximum is only raised when some query's tile maximum exceeds it by more than 8 (in log2
+// units: P <= 256, exact in fp32 and in the hi/lo split), so the rescaling pass over the 32 output accumulators leaves the loop.
+// Same masks, same dropout decisions (rng_pair over adjacent keys) and the same three-term products as the 16x16x32 kernel.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ f32x16 mfma32(const bf16x8_t& a, const bf16x8_t& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <int NSPLIT>
+__device__ __forceinline__ f32x16 mma3_32(const bf16x8_t& ah, const bf16x8_t& al, const bf16x8_t& bh, const bf16x8_t& bl, f32x16 c) {
+    if (NSPLIT == 3) {
+        c = mfma32(al, bh, c);
+        c = mfma32(ah, bl, c);
+    }
+    return mfma32(ah, bh, c);
+}
+// K image [64 keys][64 d] bf16 (128-B rows), read by rows as the A operand (lane: key = lane & 31, 16 B at d = 16 kst + 8 hi): the
+// 16-B chunk index is XOR-ed with (row >> 1) & 7, which spreads the rows of every ds_read_b128 lane group ({0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31}) over all 16 granules of the 64 banks.  V image, read transposed (4 keys x 16 d per 16-lane group): chunk bit 2
+// is flipped for rows with (row >> 1) & 1, so the four rows of a group (two per bank half) take disjoint 64-B spans.
+__device__ __forceinline__ int kimg_off(int row, int col) { return row * 128 + ((((col >> 3) ^ (row >> 1)) & 7) << 4) + ((col & 7) << 1); }
+__device__ __forceinline__ int vimg_off(int row, int col) { return row * 128 + ((((col >> 3) ^ (((row >> 1) & 1) << 2))) << 4) + ((col & 7) << 1); }
+template <int NROWS, int NSPLIT, bool VIMG, int NT = 256>
+__device__ __forceinline__ void tile_store32(const float4 (&r)[NROWS * 16 / NT], unsigned char* hi_img, unsigned char* lo_img, int t, bool split_in) {
+#pragma unroll
+    for (int i = 0; i < NROWS * 16 / NT; ++i) {
+        const int idx = t + NT * i;
+        const int row = idx >> 4, dq = (idx & 15) * 4;
+        u32x2 hi, lo;
+        if (split_in) {
+            hi[0] = __float_as_uint(r[i].x); hi[1] = __float_as_uint(r[i].y); lo[0] = __float_as_uint(r[i].z); lo[1] = __float_as_uint(r[i].w);
+        } else {
+            split4<NSPLIT>(r[i], hi, lo);
+        }
+        const int off = VIMG ? vimg_off(row, dq) : kimg_off(row, dq);
+        *reinterpret_cast<u32x2*>(hi_img + off) = hi;
+        if (NSPLIT == 3) *reinterpret_cast<u32x2*>(lo_img + off) = lo;
+    }
+}
+// lane (hi, m): V[kb + 8 (j / 4) + 4 hi + j % 4][d0 + m], j = 0..7 (kb multiple of 16, d0 of 32)
+__device__ __forceinline__ bf16x8_t vtr_frag32(const unsigned char* img, int kb, int d0, int lane) {
+    const int hi = lane >> 5, dh = (lane >> 4) & 1, li = lane & 15;
+    const int row = kb + 4 * hi + (li >> 2), col = d0 + 16 * dh + 4 * (li & 3);
+    s16x4 v0 = lds_read_tr16(img + vimg_off(row, col));
+    s16x4 v1 = lds_read_tr16(img + vimg_off(row + 8, col));
+    s16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ float half_max(float v) {         // max over the lane pair (l, l ^ 32)
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    float z = __uint_as_float(b[0]), w = __uint_as_float(b[1]);
+    asm("v_max_f32 %0, %1, %2" : "=v"(z) : "v"(z), "v"(w));
+    return z;
+}
+__device__ __forceinline__ float half_sum(float v) {
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+#define ATTN_DEFER_MAX 8.0f
+
+template <int NSPLIT>
+__global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) {
+    constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
+    constexpr int IMG = 64 * 128;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PARTS * IMG];
+    unsigned char* sK[2] = {smem, smem + (PARTS - 1) * IMG};
+    unsigned char* sV[2] = {smem + PARTS * IMG, smem + PARTS * IMG + (PARTS - 1) * IMG};
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n = lane & 31, hi = lane >> 5;
+    int bx, bh;
+    if (!xcd_remap((p.Tq + 127) / 128, p.B * p.H, bx, bh)) return;
+    if (p.causal) bx = (p.Tq + 127) / 128 - 1 - bx;
+    const int h = bh % p.H, b = bh / p.H;
+    const int qblk = bx * 128;
+    const int q0 = qblk + wave * 32;
+    const bool wave_live = __builtin_amdgcn_readfirstlane((int)(q0 < p.Tq)) != 0;
+    const int klen = p.lens_k ? min(p.Tk, p.lens_k[b]) : p.Tk;
+    int kmax = klen;
+    if (p.causal) kmax = min(kmax, qblk + 128);
+    const int nkt = (kmax + 63) / 64;
+
+    const float* Qb = p.Q + (size_t)b * p.Tq * p.ldq + h * HD;
+    const float* Kb = p.K + (size_t)b * p.Tk * p.ldk + h * HD;
+    const float* Vb = p.V + (size_t)b * p.Tk * p.ldv + h * HD;
+    const float sc = p.scale * LOG2E;
+    const bool split_in = p.qkv_split != 0;
+    const float ssc = split_in ? sc : 1.f;
+    const int q = q0 + n;
+    const bool qok = q < p.Tq;
+
+    bf16x8_t qf[4][PARTS];                 // B operand of S^T: lane holds Q[q][16 kst + 8 hi .. +7]
+#pragma unroll
+    for (int kst = 0; kst < 4; ++kst) {
+        bf16x8_t fh, fl;
+        load_frag8<NSPLIT>(Qb + (size_t)q * p.ldq + 16 * kst + 8 * hi, qok, split_in, sc, fh, fl);
+        qf[kst][0] = fh;
+        if (PARTS == 2) qf[kst][PARTS - 1] = fl;
+    }
+    // dropout: (key >> 1) = 32 kt + 2 hi + c with c = 16 t2 + 4 (i / 4) + (i % 4) / 2 < 32 in bit fields of its own, so the sum is an XOR
+    const uint32_t rkey = p.drop_thresh ? rng_row_key(p.seed, p.stream, (uint32_t)(((size_t)b * p.H + h) * p.Tq + q)) : 0u;
+    float m = NEG_BIG, lsum = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+
+    float4 rk[4], rv[4];
+    if (nkt > 0) {
+        tile_load<64>(Kb, p.ldk, min(64, p.Tk), rk, t);
+        tile_load<64>(Vb, p.ldv, min(64, p.Tk), rv, t);
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        tile_store32<64, NSPLIT, false>(rk, sK[0], sK[PARTS - 1], t, split_in);
+        tile_store32<64, NSPLIT, true>(rv, sV[0], sV[PARTS - 1], t, split_in);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            const int kr = (kt + 1) * 64;
+            tile_load<64>(Kb + (size_t)kr * p.ldk, p.ldk, min(64, p.Tk - kr), rk, t);
+            tile_load<64>(Vb + (size_t)kr * p.ldv, p.ldv, min(64, p.Tk - kr), rv, t);
+        }
+        if (wave_live) {
+        f32x16 s[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[t2][i] = 0.f;
+#pragma unroll
+            for (int kst = 0; kst < 4; ++kst) {
+                const int off = kimg_off(32 * t2 + n, 16 * kst + 8 * hi);
+                const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(sK[0] + off);
+                const bf16x8_t kl = (PARTS == 2) ? *reinterpret_cast<const bf16x8_t*>(sK[PARTS - 1] + off) : kh;
+                s[t2] = mma3_32<NSPLIT>(kh, kl, qf[kst][0], qf[kst][PARTS - 1], s[t2]);
+            }
+        }
+        const bool interior = (kt * 64 + 64 <= klen) && (!p.causal || kt * 64 + 63 <= q0);
+        auto softmax_tile = [&](auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            float tmax = NEG_BIG;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = s[t2][i];
+                    if (MASKED) {
+                        const int key = kt * 64 + 32 * t2 + 8 * (i >> 2) + 4 * hi + (i & 3);
+                        const bool valid = key < klen && (!p.causal || key <= q);
+                        v = valid ? v : NEG_BIG;
+                        s[t2][i] = v;
+                    }
+                    tmax = fmaxf(tmax, v);
+                }
+            const float ts = half_max(tmax) * ssc;
+            // The running maximum follows a query's tile maximum only once that exceeds it by more than ATTN_DEFER_MAX (P <= 2^8 meanwhile:
+            // exact in fp32 and in the hi/lo split), so alpha is exactly 1 in most iterations.  Branch-free on purpose: with the rescaling
+            // pass under a wave-uniform branch the compiler kept three copies of the 32 output accumulators (94 v_mov_b64 per iteration).
+            const float mnew = (ts > m + ATTN_DEFER_MAX) ? ts : m;
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            m = mnew;
+            lsum *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[dt] = o[dt] * alpha;
+            const uint32_t rk_it = rkey ^ (uint32_t)(kt * 32 + 2 * hi);
+            float rs = 0.f;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int ip = 0; ip < 8; ++ip) {
+                    const int i = 2 * ip;
+                    uint32_t hh = 0;
+                    if (p.drop_thresh) {
+                        hh = (rk_it ^ (uint32_t)(16 * t2 + 4 * (i >> 2) + ((i & 3) >> 1))) * 0x9E3779B1u;
+                        hh ^= hh >> 15;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const bool keep = !p.drop_thresh || (e ? rng_keep_hi(hh, p.drop_thresh) : rng_keep_lo(hh, p.drop_thresh));
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t2][i + e], ssc, -m));      // masked entries: exp2(-1e30 * ssc - m) = 0
+                        rs += pv;
+                        s[t2][i + e] = keep ? pv : 0.f;
+                    }
+                }
+            lsum += rs;
+        };
+        if (interior) softmax_tile(std::false_type{}); else softmax_tile(std::true_type{});
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                bf16x8_t ph, pl;
+                split8<NSPLIT>(make_float4(s[t2][8 * v], s[t2][8 * v + 1], s[t2][8 * v + 2], s[t2][8 * v + 3]),
+                               make_float4(s[t2][8 * v + 4], s[t2][8 * v + 5], s[t2][8 * v + 6], s[t2][8 * v + 7]), ph, pl);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x8_t xh = vtr_frag32(sV[0], 32 * t2 + 16 * v, 32 * dt, lane);
+                    const bf16x8_t xl = (PARTS == 2) ? vtr_frag32(sV[PARTS - 1], 32 * t2 + 16 * v, 32 * dt, lane) : xh;
+                    o[dt] = mma3_32<NSPLIT>(xh, xl, ph, pl, o[dt]);
+                }
+            }
+        }   // wave_live
+        __syncthreads();
+    }
+    // ---- epilogue: lane holds O^T[d = 32 dt + 8 (i / 4) + 4 hi + i % 4][q] --------------------------------------
+    const float ltot = half_sum(lsum);
+    if (qok) {
+        const float f = ltot > 0.f ? p.drop_scale / ltot : 0.f;
+        float* dst = p.O + ((size_t)b * p.Tq + q) * p.ldo + h * HD + 4 * hi;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+                *reinterpret_cast<float4*>(dst + 32 * dt + 8 * i4) = make_float4(o[dt][4 * i4] * f, o[dt][4 * i4 + 1] * f, o[dt][4 * i4 + 2] * f, o[dt][4 * i4 + 3] * f);
+        if (hi == 0) p.LSE[((size_t)b * p.H + h) * p.Tq + q] = (m + log2f(ltot)) * LN2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // dK / dV.  grid (ceil(Tk/128), H, B); wave w owns keys [128*bx + 32w, +32) and keeps dK^T, dV^T [64 x 32] in
 // accumulators while the workgroup sweeps 32-query tiles of Q and dO through LDS.
 // ------------------------------------------------------------------------------------------------------------
@@ -387,17 +624,24 @@ __global__ __launch_bounds__(128 * (4 / QS), (QS == 1 ? 4 : 2)) void attn_q_kern
 // K image: dQ[32 q x 16 d (slice w)] = dS^T-fragments (transposed reads) x K-fragments (transposed reads, same
 // key permutation).  The result is the workgroup's share of dQ; key blocks are summed with fp32 atomics (each wave-instruction
 // adds 4 rows x 64 contiguous bytes), dQ is zeroed by the caller.
-template <int NSPLIT, int FUSE_DQ>
+// PLO = 0 (the shipped one-pass form): the probabilities P and the score gradients dS, which the kernel makes itself, enter the dV, dK and
+// dQ products as ONE bf16 part each -- the terms P_lo.dO_hi, dS_lo.Q_hi and dS_lo.K_hi are left out: 12 MFMAs per tile product instead of
+// 15, no low-part split of P and dS (2.5 vector instructions per score each), half the dS image.  tools/oracle_emu_attn_terms.py
+// (fp64 oracle, the kernels' products emulated term by term) prices it: gradient error against fp64 median 1.6e-4 -> 1.7e-4 / 4.5e-5 ->
+// 5.0e-5, the worst gradient-norm error unchanged (1.6e-4; 1.2e-3 -> 1.5e-3 on the tensors DESIGN section 3 lists), outputs untouched.
+// (The FORWARD's P_lo.V_hi term is a different matter: without it the outputs move by 1.2e-3 - 2.1e-3, beyond north_star's 1e-3; kept.)
+template <int NSPLIT, int FUSE_DQ, int PLO>
 __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
     constexpr int PARTS = (NSPLIT == 3) ? 2 : 1;
+    constexpr int SPARTS = PLO ? PARTS : 1;                   // parts of P / dS
     constexpr int IMG = 32 * ALD * 2;
     constexpr int IMG128 = 128 * ALD * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PARTS * IMG + (FUSE_DQ ? 2 * PARTS * IMG128 : 0)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PARTS * IMG + (FUSE_DQ ? (PARTS + SPARTS) * IMG128 : 0)];
     unsigned char* sQ[2] = {smem, smem + (PARTS - 1) * IMG};
     unsigned char* sD[2] = {smem + PARTS * IMG, smem + PARTS * IMG + (PARTS - 1) * IMG};
     unsigned char* const fbase = smem + 2 * PARTS * IMG;
     unsigned char* sKs[2] = {fbase, fbase + (PARTS - 1) * IMG128};                               // K * scale, [128 keys][64 d]
-    unsigned char* sS[2] = {fbase + PARTS * IMG128, fbase + PARTS * IMG128 + (PARTS - 1) * IMG128};   // dS, [128 keys][buf*32 + q]
+    unsigned char* sS[2] = {fbase + PARTS * IMG128, fbase + PARTS * IMG128 + (SPARTS - 1) * IMG128};  // dS, [128 keys][buf*32 + q]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
     int bx, bh;
@@ -480,8 +724,12 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
 #pragma unroll
             for (int qs = 0; qs < 2; ++qs) {
                 const bf16x8_t ah = tr_frag(sS[0], 32 * kk, 32 * buf + 16 * qs, l15, g);
-                const bf16x8_t al = (PARTS == 2) ? tr_frag(sS[PARTS - 1], 32 * kk, 32 * buf + 16 * qs, l15, g) : ah;
-                dq[qs] = mma3<NSPLIT>(ah, al, bh, bl, dq[qs]);          // D[m = q][n = d]
+                if (SPARTS == 2) {
+                    const bf16x8_t al = tr_frag(sS[SPARTS - 1], 32 * kk, 32 * buf + 16 * qs, l15, g);
+                    dq[qs] = mma3<NSPLIT>(ah, al, bh, bl, dq[qs]);          // D[m = q][n = d]
+                } else {
+                    dq[qs] = mma2_a<NSPLIT>(ah, bh, bl, dq[qs]);
+                }
             }
         }
         float* dqb = p.O + (size_t)b * p.Tq * p.ldo + h * HD + 16 * wave + l15;
@@ -572,22 +820,22 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
         };
         if (interior) pointwise(std::false_type{}); else pointwise(std::true_type{});
         // ---- dV^T += dO^T . Pd ;  dK^T += Q^T . dS  (sum over the 32 queries of the tile) ------------------
-        bf16x8_t pf[2][PARTS], sf[2][PARTS];
+        bf16x8_t pf[2][SPARTS], sf[2][SPARTS];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8_t hi, lo;
-            pack_acc<NSPLIT>(s[0][ks], s[1][ks], hi, lo);
-            pf[ks][0] = hi; if (PARTS == 2) pf[ks][PARTS - 1] = lo;
-            pack_acc<NSPLIT>(dp[0][ks], dp[1][ks], hi, lo);
-            sf[ks][0] = hi; if (PARTS == 2) sf[ks][PARTS - 1] = lo;
+            pack_acc<(SPARTS == 2 ? NSPLIT : 1)>(s[0][ks], s[1][ks], hi, lo);
+            pf[ks][0] = hi; if (SPARTS == 2) pf[ks][SPARTS - 1] = lo;
+            pack_acc<(SPARTS == 2 ? NSPLIT : 1)>(dp[0][ks], dp[1][ks], hi, lo);
+            sf[ks][0] = hi; if (SPARTS == 2) sf[ks][SPARTS - 1] = lo;
             if (FUSE_DQ) {     // the same words, as row `key` of the dS image: queries 4g..4g+3 of both 16-row sub-tiles
                 const int row = wave * 32 + 16 * ks + l15, col = 32 * (qt & 1) + 4 * g;
                 const u32x4 hw = __builtin_bit_cast(u32x4, hi), lw = __builtin_bit_cast(u32x4, lo);
                 *reinterpret_cast<u32x2*>(sS[0] + img_off(row, col)) = (u32x2){hw[0], hw[1]};
                 *reinterpret_cast<u32x2*>(sS[0] + img_off(row, col + 16)) = (u32x2){hw[2], hw[3]};
-                if (PARTS == 2) {
-                    *reinterpret_cast<u32x2*>(sS[PARTS - 1] + img_off(row, col)) = (u32x2){lw[0], lw[1]};
-                    *reinterpret_cast<u32x2*>(sS[PARTS - 1] + img_off(row, col + 16)) = (u32x2){lw[2], lw[3]};
+                if (SPARTS == 2) {
+                    *reinterpret_cast<u32x2*>(sS[SPARTS - 1] + img_off(row, col)) = (u32x2){lw[0], lw[1]};
+                    *reinterpret_cast<u32x2*>(sS[SPARTS - 1] + img_off(row, col + 16)) = (u32x2){lw[2], lw[3]};
                 }
             }
         }
@@ -599,8 +847,13 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
             const bf16x8_t ql = (PARTS == 2) ? tr_frag(sQ[PARTS - 1], 0, 16 * dt, l15, g) : qh;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                dv[dt][ks] = mma3<NSPLIT>(doh, dol, pf[ks][0], pf[ks][PARTS - 1], dv[dt][ks]);
-                dk[dt][ks] = mma3<NSPLIT>(qh, ql, sf[ks][0], sf[ks][PARTS - 1], dk[dt][ks]);
+                if (SPARTS == 2) {
+                    dv[dt][ks] = mma3<NSPLIT>(doh, dol, pf[ks][0], pf[ks][SPARTS - 1], dv[dt][ks]);
+                    dk[dt][ks] = mma3<NSPLIT>(qh, ql, sf[ks][0], sf[ks][SPARTS - 1], dk[dt][ks]);
+                } else {
+                    dv[dt][ks] = mma2_b<NSPLIT>(doh, dol, pf[ks][0], dv[dt][ks]);
+                    dk[dt][ks] = mma2_b<NSPLIT>(qh, ql, sf[ks][0], dk[dt][ks]);
+                }
             }
         }
         }   // wave_live
@@ -674,6 +927,15 @@ static int fill_common(AttnParams& p, const float* Q, int ldq, const float* K, i
     return UNAST_OK;
 }
 
+// 1 (default, UNAST_ATTN_FWD_M32): forward on 32x32x16 MFMAs (attn_fwd32_kernel); 0: the 16x16x32 kernel.  unast_attn_fwd_variant
+// switches at run time (tests compare the two).
+static int g_attn_fwd_m32 = [] { const char* e = getenv("UNAST_ATTN_FWD_M32"); return (e && e[0] == '0') ? 0 : 1; }();
+extern "C" int unast_attn_fwd_variant(int m32) {
+    const int old = g_attn_fwd_m32;
+    if (m32 >= 0) g_attn_fwd_m32 = m32 ? 1 : 0;
+    return old;
+}
+
 extern "C" int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                               float* LSE, const int* lens_k, int B, int H, int Tq, int Tk, int head_dim, int causal, float scale,
                               float drop_p, unsigned int seed, unsigned int stream_id, int qkv_split, hipStream_t stream) {
@@ -687,6 +949,11 @@ extern "C" int unast_attn_fwd(int nsplit, const float* Q, int ldq, const float* 
     // 800x800, every config-3 shape within 3 %) -- occupancy is not what bounds this kernel -- so the 4-wave form stays the default.
     static const bool q16 = [] { const char* e = getenv("UNAST_ATTN_FWD_Q16"); return e && e[0] == '1'; }();
     dim3 grid(xcd_grid((Tq + 127) / 128, B * H));
+    if (g_attn_fwd_m32 && !q16) {
+        if (nsplit == 3) hipLaunchKernelGGL((attn_fwd32_kernel<3>), grid, dim3(256), 0, stream, p);
+        else             hipLaunchKernelGGL((attn_fwd32_kernel<1>), grid, dim3(256), 0, stream, p);
+        return unast_check_launch("unast_attn_fwd");
+    }
     if (nsplit == 3) if (q16) hipLaunchKernelGGL((attn_q_kernel<3, 0, 1>), grid, dim3(512), 0, stream, p); else hipLaunchKernelGGL((attn_q_kernel<3, 0, 2>), grid, dim3(256), 0, stream, p);
     else             if (q16) hipLaunchKernelGGL((attn_q_kernel<1, 0, 1>), grid, dim3(512), 0, stream, p); else hipLaunchKernelGGL((attn_q_kernel<1, 0, 2>), grid, dim3(256), 0, stream, p);
     return unast_check_launch("unast_attn_fwd");
@@ -710,15 +977,16 @@ extern "C" int unast_attn_bwd(int nsplit, const float* Q, int ldq, const float* 
     p.dO = dO; p.lddo = lddo; p.LSE = const_cast<float*>(LSE); p.Delta = delta_ws;
     p.O = dQ; p.ldo = lddq; p.dK = dK; p.dV = dV; p.lddk = lddk; p.lddv = lddv;
     dim3 gq(xcd_grid((Tq + 127) / 128, B * H)), gk(xcd_grid((Tk + 127) / 128, B * H));
+    // fused: 0 = dQ kernel + dK/dV kernel; 1 = one pass, all three terms in every product; 2 = one pass, P and dS as one bf16 part
     if (fused) {
-        if (nsplit == 3) hipLaunchKernelGGL((attn_dkv_kernel<3, 1>), gk, dim3(256), 0, stream, p);
-        else             hipLaunchKernelGGL((attn_dkv_kernel<1, 1>), gk, dim3(256), 0, stream, p);
+        if (nsplit == 3) { if (fused == 1) hipLaunchKernelGGL((attn_dkv_kernel<3, 1, 1>), gk, dim3(256), 0, stream, p); else hipLaunchKernelGGL((attn_dkv_kernel<3, 1, 0>), gk, dim3(256), 0, stream, p); }
+        else             hipLaunchKernelGGL((attn_dkv_kernel<1, 1, 1>), gk, dim3(256), 0, stream, p);
     } else if (nsplit == 3) {
         hipLaunchKernelGGL((attn_q_kernel<3, 1, 2>), gq, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL((attn_dkv_kernel<3, 0>), gk, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_dkv_kernel<3, 0, 1>), gk, dim3(256), 0, stream, p);
     } else {
         hipLaunchKernelGGL((attn_q_kernel<1, 1, 2>), gq, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL((attn_dkv_kernel<1, 0>), gk, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_dkv_kernel<1, 0, 1>), gk, dim3(256), 0, stream, p);
     }
     return unast_check_launch("unast_attn_bwd");
 }

@@ -426,7 +426,8 @@ def attn_bwd(Q, K, V, O, dO, LSE, delta_ws, dQ, dK, dV, lens_k, B, H, Tq, Tk, ca
     check(lib().unast_attn_bwd(nsplit or config.NSPLIT, _p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0),
                                _p(dO), dO.stride(0), _p(LSE), _p(delta_ws), _p(dQ), dQ.stride(0), _p(dK), dK.stride(0), _p(dV),
                                dV.stride(0), _p(lens_k), B, H, Tq, Tk, 64, int(causal), 0.125, drop_p, seed & 0xFFFFFFFF, stream_id,
-                               int(config.ATTN_FUSED_BWD), int(qkv_split), _p(lens_q) if config.ATTN_FUSED_BWD else None, _stream()), "unast_attn_bwd")
+                               (2 if config.ATTN_BWD_TERMS == 2 else 1) if config.ATTN_FUSED_BWD else 0, int(qkv_split),
+                               _p(lens_q) if config.ATTN_FUSED_BWD else None, _stream()), "unast_attn_bwd")
 
 
 # ---- normalisation -----------------------------------------------------------------------------------------
