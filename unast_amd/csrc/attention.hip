@@ -508,15 +508,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
         tile_load<64>(Kb, p.ldk, min(64, p.Tk), rk, t);
         tile_load<64>(Vb, p.ldv, min(64, p.Tk), rv, t);
     }
+    // KO_*: timing-only knock-out builds (tools/attn_knockout.sh; never defined in the shipped library; results are wrong with any of them)
     for (int kt = 0; kt < nkt; ++kt) {
+#ifndef KO_LDS_STORE
         tile_store32<64, NSPLIT, false>(rk, sK[0], sK[PARTS - 1], t, split_in);
         tile_store32<64, NSPLIT, true>(rv, sV[0], sV[PARTS - 1], t, split_in);
+#endif
+#ifndef KO_BARRIER
         __syncthreads();
+#endif
+#ifndef KO_GLOAD
         if (kt + 1 < nkt) {
             const int kr = (kt + 1) * 64;
             tile_load<64>(Kb + (size_t)kr * p.ldk, p.ldk, min(64, p.Tk - kr), rk, t);
             tile_load<64>(Vb + (size_t)kr * p.ldv, p.ldv, min(64, p.Tk - kr), rv, t);
         }
+#endif
         if (wave_live) {
         f32x16 s[2];
 #pragma unroll
@@ -528,7 +535,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
                 const int off = kimg_off(32 * t2 + n, 16 * kst + 8 * hi);
                 const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(sK[0] + off);
                 const bf16x8_t kl = (PARTS == 2) ? *reinterpret_cast<const bf16x8_t*>(sK[PARTS - 1] + off) : kh;
+#ifdef KO_SMFMA
+                s[t2][kst] += __builtin_bit_cast(f32x4, kh)[0] + __builtin_bit_cast(f32x4, kl)[1];
+#else
                 s[t2] = mma3_32<NSPLIT>(kh, kl, qf[kst][0], qf[kst][PARTS - 1], s[t2]);
+#endif
             }
         }
         const bool interior = (kt * 64 + 64 <= klen) && (!p.causal || kt * 64 + 63 <= q0);
@@ -580,7 +591,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
                 }
             lsum += rs;
         };
+#ifndef KO_SOFTMAX
         if (interior) softmax_tile(std::false_type{}); else softmax_tile(std::true_type{});
+#endif
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -592,11 +605,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
                 for (int dt = 0; dt < 2; ++dt) {
                     const bf16x8_t xh = vtr_frag32(sV[0], 32 * t2 + 16 * v, 32 * dt, lane);
                     const bf16x8_t xl = (PARTS == 2) ? vtr_frag32(sV[PARTS - 1], 32 * t2 + 16 * v, 32 * dt, lane) : xh;
+#ifdef KO_PVMFMA
+                    o[dt][2 * t2 + v] += __builtin_bit_cast(f32x4, xh)[0] + __builtin_bit_cast(f32x4, xl)[1] + __builtin_bit_cast(f32x4, ph)[0] + __builtin_bit_cast(f32x4, pl)[1];
+#else
                     o[dt] = mma3_32<NSPLIT>(xh, xl, ph, pl, o[dt]);
+#endif
                 }
             }
         }   // wave_live
+#ifndef KO_BARRIER
         __syncthreads();
+#endif
     }
     // ---- epilogue: lane holds O^T[d = 32 dt + 8 (i / 4) + 4 hi + i % 4][q] --------------------------------------
     const float ltot = half_sum(lsum);
@@ -788,35 +807,58 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
         // ---- P (dropped) and dS; lane: key = k0+16ks+l15, q = 32qt+16qs+4g+r ------------------------------
         // interior (wave-uniform): every (query, key) pair of this 32x32 sub-problem is unmasked
         const bool interior = (qt * 32 + 32 <= p.Tq) && (k0 + 32 <= klen) && (!p.causal || k0 + 31 <= qt * 32);
+        // Dropout decisions: one hash serves the two adjacent keys of a lane pair (rng_pair), and here the key sits on the lane -- so the
+        // even lane of a pair hashes rows r = 0, 1 of each 4-row group, the odd lane rows 2, 3, and a quad-permute DPP move hands each
+        // lane its partner's two (half the multiplies of hashing per element: 16 v_mul_lo_u32 fewer per 32 x 32 tile and wave).
         auto pointwise = [&](auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
+            const int par = l15 & 1;
+            const uint32_t sh16 = par ? 0u : 16u, thr_hi = p.drop_thresh << 16;
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs)
+            for (int qs = 0; qs < 2; ++qs) {
+                float l2[4], de[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = qt * 32 + 16 * qs + 4 * g + r;
-                    const bool qok = !MASKED || q < p.Tq;
-                    const float l2 = __shfl(rl_cur, 16 * qs + 4 * g + r, 64);
-                    const float de = __shfl(rl_cur, 32 + 16 * qs + 4 * g + r, 64);
-                    const uint32_t rkey = p.drop_thresh ? (uint32_t)__shfl((int)rk_cur, 16 * qs + 4 * g + r, 64) : 0u;
+                    l2[r] = __shfl(rl_cur, 16 * qs + 4 * g + r, 64);
+                    de[r] = __shfl(rl_cur, 32 + 16 * qs + 4 * g + r, 64);
+                }
+                uint32_t rkm[2] = {0u, 0u};
+                if (p.drop_thresh) {
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const int key = k0 + 16 * ks + l15;
-                        float pv = __builtin_amdgcn_exp2f(s[qs][ks][r] * sc - l2);
+                    for (int j = 0; j < 2; ++j) rkm[j] = (uint32_t)__shfl((int)rk_cur, 16 * qs + 4 * g + 2 * par + j, 64);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int key = k0 + 16 * ks + l15;
+                    uint32_t hh[4] = {0u, 0u, 0u, 0u};
+                    if (p.drop_thresh) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const uint32_t hm = rng_pair(rkm[j], (uint32_t)key);
+                            hh[j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xA0, 0xF, 0xF, true);          // quad_perm [0,0,2,2]: the even lane's
+                            hh[2 + j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xF5, 0xF, 0xF, true);      // quad_perm [1,1,3,3]: the odd lane's
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(s[qs][ks][r] * sc - l2[r]);
                         if (MASKED) {
-                            const bool valid = qok && key < klen && (!p.causal || key <= q);
+                            const int q = qt * 32 + 16 * qs + 4 * g + r;
+                            const bool valid = q < p.Tq && key < klen && (!p.causal || key <= q);
                             pv = valid ? pv : 0.f;
                         }
                         float pd = pv, dpe = dp[qs][ks][r];
                         if (p.drop_thresh) {
-                            const bool keep = rng_keep(rkey, (uint32_t)key, p.drop_thresh);
+                            // this lane's half of the pair hash (odd key: upper, even key: lower) moved to the top and compared as a whole word
+                            const bool keep = (hh[r] << sh16) >= thr_hi;
                             pd = keep ? pv : 0.f;
                             dpe = keep ? dpe : 0.f;
                         }
                         s[qs][ks][r] = pd;                       // kept probabilities (B operand of dV; 1/(1-p) is applied to dV in the epilogue)
-                        dp[qs][ks][r] = pv * __builtin_fmaf(dpe, p.drop_scale, -de);         // dS (B operand of dK)
+                        dp[qs][ks][r] = pv * __builtin_fmaf(dpe, p.drop_scale, -de[r]);         // dS (B operand of dK)
                     }
                 }
+            }
         };
         if (interior) pointwise(std::false_type{}); else pointwise(std::true_type{});
         // ---- dV^T += dO^T . Pd ;  dK^T += Q^T . dS  (sum over the 32 queries of the tile) ------------------
