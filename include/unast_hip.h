@@ -340,6 +340,9 @@ int unast_graph_plan_destroy(int64_t plan);
  * given here (allreduces: how many such nodes the plan holds). */
 int unast_graph_plan_allreduces(int64_t plan);
 int unast_graph_plan_set_comm(int64_t plan, int64_t comm);
+/* The element counts of the plan's gradient exchanges in the order the replay issues them (up to n written to out; returns how many the
+ * plan holds).  Collectives of one communicator pair up across ranks by issue order: tests compare this list with the eager step's. */
+int unast_graph_plan_allreduce_counts(int64_t plan, long long* out, int n);
 
 /* Data-parallel gradient exchange over RCCL / xGMI (csrc/comm.cpp).  New with respect to the reference, which is single-device
  * (src/utils.py:101-106); the order it has to keep -- generator update before the discriminator phase -- is src/train.py:628-637.

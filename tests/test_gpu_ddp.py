@@ -29,7 +29,9 @@ args = make_args(num_layers=1, ae_steps=1, sp_steps=0 if CM else 1, d_steps=1, c
 utils.set_seed(7); utils.set_deterministic(True)
 _, _, model, opt, sched = train.initialize_model(args)
 opt.param_groups[0]["lr"] = 1e-3
-batch = tuple(torch.from_numpy(x) for x in synth_batch(2, 16, 40, seed=rank, ragged=True))      # different data per rank
+SHAPES = os.environ.get("TEST_RANK_SHAPES", "0") == "1"          # each rank pads to its own lengths, as ranks of a real job do
+shape = (2, 16, 40) if (rank == 0 or not SHAPES) else (3, 12, 56)
+batch = tuple(torch.from_numpy(x) for x in synth_batch(*shape, seed=rank, ragged=True))      # different data per rank
 losses = defaultdict(list)
 from unast_amd import ddp
 gnorms = []
@@ -47,22 +49,45 @@ if CM:
     so, to = model.speech_m.infer_sequence, model.text_m.infer_sequence
     model.speech_m.infer_sequence = lambda memory, masks, max_len=6: so(memory, masks, max_len)
     model.text_m.infer_sequence = lambda memory, masks, max_len=6: to(memory, masks, max_len)
+EAGER_RANK = int(os.environ.get("TEST_EAGER_RANK", "-1"))          # this rank never captures: it runs the same shifted bodies kernel by kernel
 if GRAPH:
     from unast_amd.graphed import GraphedTrainStep
     stepper = GraphedTrainStep(model, opt, None, args)
     assert stepper.capturable(), "the native communicator should make the distributed step capturable"
+    if rank == EAGER_RANK:
+        class _Never(dict):
+            def __contains__(self, k): return False
+        stepper.warmed = _Never()
+    body_logs = []
     for it in range(5):
+        n0 = len(ddp._State.log)
         stepper(losses, batches, it)
+        body_logs.append([b - a for (_, a, b) in ddp._State.log[n0:]])
     stepper.flush(losses)
-    rec = next(iter(stepper.graphs.values()))
-    assert rec.plan and rec.plan_info["allreduces"] >= 5, rec.plan_info
-    print("plan", rec.plan_info)
+    if rank == EAGER_RANK:
+        assert stepper.stats["replays"] == 0 and stepper.stats["eager_bodies"] == 4, stepper.stats
+        counts = body_logs[-1]                       # what the last shifted body issued eagerly, in issue order
+    else:
+        rec = next(iter(stepper.graphs.values()))
+        assert rec.plan and rec.plan_info["allreduces"] >= 5, rec.plan_info
+        print("plan", rec.plan_info)
+        import ctypes
+        from unast_amd._lib import lib
+        arr = (ctypes.c_longlong * 64)()
+        n = lib().unast_graph_plan_allreduce_counts(rec.plan, ctypes.addressof(arr), 64)
+        counts = [int(arr[i]) for i in range(n)]
+        assert n == rec.plan_info["allreduces"] and stepper.stats["replays"] >= 3, (n, stepper.stats)
+    if world > 1:                                    # collectives pair up by issue order: replayed plan == eager issue == the other rank's
+        objs = [None] * world
+        dist.all_gather_object(objs, counts)
+        assert all(o == counts for o in objs), objs
+        print("collective order", counts)
 else:
     for it in range(int(os.environ.get("TEST_STEPS", "2"))):
         train.train_step(losses, model, opt, None, batches, it, args, defer_d_phase=bool(it))
 from unast_amd.engine import join_streams
 join_streams(); torch.cuda.synchronize()
-if os.environ.get("TEST_BACKEND", "gloo") == "nccl" and os.environ.get("UNAST_NATIVE_COMM", "1") != "0":
+if (os.environ.get("TEST_BACKEND", "gloo") == "nccl" or os.environ.get("UNAST_COMM_LIB")) and os.environ.get("UNAST_NATIVE_COMM", "1") != "0":
     assert ddp._Native.handle and ddp._Native.issued > 0, "the exchange should have gone through unast_allreduce"
 labels = [l[0] for l in ddp._State.log]
 if GRAPH or os.environ.get("TEST_STEPS"):
@@ -89,6 +114,7 @@ if world > 1:
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     assert torch.equal(gathered[0], gathered[1]), "ranks diverged after a data-parallel step"
+    assert torch.isfinite(flat).all(), "non-finite parameters (the test communicator fills a mismatched collective with NaN)"
     l = torch.tensor([float(losses["s_ae"][0])]); ls = [torch.empty(1) for _ in range(world)]; dist.all_gather(ls, l)
     assert ls[0].item() != ls[1].item(), "ranks should have seen different batches"
 assert torch.isfinite(flat).all()
@@ -163,6 +189,74 @@ def test_single_rank_nccl_replayed_step_issues_the_collectives_from_cpp(tmp_path
         assert len(a["losses"][k]) == len(b["losses"][k]) == 5, (k, len(a["losses"][k]), len(b["losses"][k]))
         for x, y in zip(a["losses"][k], b["losses"][k]):
             assert abs(x - y) < 2e-3 * max(1.0, abs(y)), (k, a["losses"][k], b["losses"][k])
+
+
+SHIM = os.path.join(ROOT, "tests", "native", "libfake_rccl.so")
+
+
+def _need_shim():
+    if not os.path.exists(SHIM):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "unast_amd", "csrc"), "../../tests/native/libfake_rccl.so"], check=True)
+
+
+def _close(a, b, steps=5):
+    for k in a["losses"]:
+        assert len(a["losses"][k]) == len(b["losses"][k]) == steps, (k, len(a["losses"][k]), len(b["losses"][k]))
+        for x, y in zip(a["losses"][k], b["losses"][k]):
+            assert abs(x - y) < 2e-3 * max(1.0, abs(y)), (k, a["losses"][k], b["losses"][k])
+
+
+@pytest.mark.parametrize("jitter", ["0", "200"])
+def test_two_ranks_replayed_step_with_collectives_from_cpp(tmp_path, jitter):
+    """The path `bench.py --gpus N` takes, with TWO ranks: unast_comm_init with world = 2 and a broadcast unique id, the step captured with
+    marker nodes, replayed by csrc/graph_exec.cpp which issues unast_allreduce at the markers.  RCCL refuses two ranks on one device, so
+    csrc/comm.cpp binds tests/native/fake_rccl.cpp (UNAST_COMM_LIB: host-staged all-reduce with RCCL's stream semantics, which reports a
+    collective whose size differs between ranks).  Inside the workers: the same collective order on both ranks, parameters bit-equal
+    across ranks after five steps; here: equal to the blocking gloo exchange of the eager step.  With STREAM_JITTER the streams of the
+    two ranks are shifted against each other at random: no hang, same result."""
+    import torch
+    _need_shim()
+    _run(tmp_path, 2, 29561 + int(jitter) % 7, TEST_GRAPH="1", UNAST_COMM_LIB=SHIM, UNAST_STREAM_JITTER=jitter, TEST_SAVE=str(tmp_path / "g"))
+    _run(tmp_path, 2, 29571 + int(jitter) % 7, UNAST_DDP_OVERLAP="0", TEST_STEPS="5", TEST_SAVE=str(tmp_path / "e"))
+    _close(torch.load(str(tmp_path / "g") + ".0"), torch.load(str(tmp_path / "e") + ".0"))
+    _close(torch.load(str(tmp_path / "g") + ".1"), torch.load(str(tmp_path / "e") + ".1"))
+
+
+def test_two_ranks_one_replays_one_runs_eagerly_with_other_shapes(tmp_path):
+    """Ranks decide eager / capture / replay from their OWN batch shapes (unast_amd/graphed.py), so one rank may replay a plan while another
+    issues the same step kernel by kernel from ddp._issue on the same communicator: both must produce the same sequence of collectives.
+    Rank 1 here has other padded lengths and never captures; rank 0 replays.  The workers compare the order (plan order on rank 0, eager
+    issue order on rank 1) and end with bit-equal parameters; the test communicator would fill a mismatched collective with NaN."""
+    import torch
+    _need_shim()
+    _run(tmp_path, 2, 29581, TEST_GRAPH="1", UNAST_COMM_LIB=SHIM, TEST_RANK_SHAPES="1", TEST_EAGER_RANK="1", TEST_SAVE=str(tmp_path / "g"))
+    _run(tmp_path, 2, 29583, UNAST_DDP_OVERLAP="0", TEST_STEPS="5", TEST_RANK_SHAPES="1", TEST_SAVE=str(tmp_path / "e"))
+    _close(torch.load(str(tmp_path / "g") + ".0"), torch.load(str(tmp_path / "e") + ".0"))
+
+
+def test_native_eager_exchange_two_ranks(tmp_path):
+    """The eager step with the C ABI's communicator (event-chained unast_allreduce calls from ddp._issue) on two ranks == the blocking gloo exchange."""
+    import torch
+    _need_shim()
+    _run(tmp_path, 2, 29585, UNAST_COMM_LIB=SHIM, TEST_SAVE=str(tmp_path / "n"))
+    _run(tmp_path, 2, 29587, UNAST_DDP_OVERLAP="0", TEST_SAVE=str(tmp_path / "b"))
+    _same(torch.load(str(tmp_path / "n") + ".0"), torch.load(str(tmp_path / "b") + ".0"))
+
+
+def test_bench_two_ranks_torchrun_replayed_collectives():
+    """bench.py as the driver launches it for N = 2, ranks sharing the one GPU over gloo + the test communicator: the line says the step was
+    replayed with its exchanges issued from C++."""
+    _need_shim()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29589",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--backend", "gloo", "--share-gpu", "--launch", "graph"]
+    out = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, UNAST_COMM_LIB=SHIM, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["losses_finite"]
+    assert "C ABI" in d["gradient_exchange"] and "replay" in d["launch_mode"], (d["gradient_exchange"], d["launch_mode"])
+    assert d["graph_replay"]["allreduces"] >= 5, d["graph_replay"]
 
 
 def test_bench_single_rank_torchrun_nccl():

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 #include "../../include/unast_hip.h"
@@ -40,7 +41,14 @@ bool rccl_load() {
     if (g_rccl.lib) return true;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* lib = nullptr;
-    for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;       // a copy the process already carries
+    // UNAST_COMM_LIB (tests only): another library with the same five entry points -- tests/native/fake_rccl.cpp stages the all-reduce through
+    // host shared memory so that several ranks sharing ONE GPU can rehearse this path (RCCL refuses two ranks on one device)
+    const char* override_path = getenv("UNAST_COMM_LIB");
+    if (override_path && override_path[0]) {
+        lib = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { unast_set_error(UNAST_ERR_LAUNCH, "unast_comm: UNAST_COMM_LIB=%s could not be loaded (%s)", override_path, dlerror()); return false; }
+    }
+    if (!lib) for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;       // a copy the process already carries
     if (!lib) for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!lib) { unast_set_error(UNAST_ERR_LAUNCH, "unast_comm: librccl.so not found (%s)", dlerror()); return false; }
     g_rccl.get_id = (fn_get_id)dlsym(lib, "ncclGetUniqueId");

@@ -162,6 +162,15 @@ extern "C" int unast_graph_plan_allreduces(int64_t handle) {
     return plan ? plan->allreduces : -1;
 }
 
+extern "C" int unast_graph_plan_allreduce_counts(int64_t handle, long long* out, int n) {
+    Plan* plan = (Plan*)(intptr_t)handle;
+    UNAST_REQUIRE(plan && (out || n == 0), "unast_graph_plan_allreduce_counts: bad arguments");
+    int i = 0;
+    for (const PlanOp& op : plan->ops)
+        if (op.kind == OP_ALLREDUCE) { if (i < n) out[i] = op.rcount; ++i; }
+    return i;
+}
+
 extern "C" int unast_graph_plan_set_comm(int64_t handle, int64_t comm) {
     Plan* plan = (Plan*)(intptr_t)handle;
     UNAST_REQUIRE(plan, "unast_graph_plan_set_comm: null plan");
@@ -178,6 +187,7 @@ extern "C" int unast_graph_plan_replay(int64_t handle, hipStream_t origin) {
     for (auto s : plan->streams) hipStreamWaitEvent(s, plan->begin, 0);
     size_t ar_i = 0;
     int ar_prev_stream = -1;
+    int rc = UNAST_OK;
     for (const PlanOp& op : plan->ops) {
         hipStream_t s = plan->streams[op.stream];
         hipError_t e = hipSuccess;
@@ -193,23 +203,29 @@ extern "C" int unast_graph_plan_replay(int64_t handle, hipStream_t origin) {
             case OP_WAIT: e = hipStreamWaitEvent(s, plan->events[op.event], 0); break;
             case OP_ALLREDUCE: {
                 // Collectives of one RCCL communicator must not run concurrently nor in an order that differs between ranks: whatever streams
-                // the layout put them on, each waits for the one issued before it (plan order is the same on every rank: same capture).
+                // the layout put them on, each waits for the one issued before it (plan order = capture order: graph_layout.h takes the
+                // smallest node index among the ready ones, and hipGraphGetNodes lists nodes as they were captured -- the order in which the
+                // eager step's ddp._issue calls come, so a rank that replays and a rank that runs the same step eagerly pair up).
                 if (ar_i > 0 && ar_prev_stream != op.stream) e = hipStreamWaitEvent(s, plan->ar_done[ar_i - 1], 0);
                 if (e != hipSuccess) break;
-                const int rc = unast_allreduce(plan->comm, op.rbuf, op.rcount, s);
-                if (rc) return rc;
+                rc = unast_allreduce(plan->comm, op.rbuf, op.rcount, s);
+                if (rc) break;
                 e = hipEventRecord(plan->ar_done[ar_i], s);
                 ar_prev_stream = op.stream; ++ar_i;
                 break;
             }
             default: break;
         }
-        if (e != hipSuccess) return unast_set_error(UNAST_ERR_LAUNCH, "unast_graph_plan_replay: op kind %d failed: %s", op.kind, hipGetErrorString(e));
+        if (rc) break;
+        if (e != hipSuccess) { rc = unast_set_error(UNAST_ERR_LAUNCH, "unast_graph_plan_replay: op kind %d failed: %s", op.kind, hipGetErrorString(e)); break; }
     }
+    // Also after a failure: the caller's stream must not run ahead of what the plan streams already hold (the caller raises; kernels of
+    // the failed replay may still be running against the buffers it is about to free or reuse).
     for (size_t t = 0; t < plan->streams.size(); ++t) {
-        hipEventRecord(plan->ends[t], plan->streams[t]);
-        hipStreamWaitEvent(origin, plan->ends[t], 0);
+        (void)hipEventRecord(plan->ends[t], plan->streams[t]);
+        (void)hipStreamWaitEvent(origin, plan->ends[t], 0);
     }
+    if (rc) return rc;
     return unast_check_launch("unast_graph_plan_replay");
 }
 

@@ -67,7 +67,9 @@ def native_comm():
         return 0
     _Native.tried = True
     from . import config
-    if not config.NATIVE_COMM or dist.get_backend() != "nccl" or not torch.cuda.is_available():
+    import os
+    shim = bool(os.environ.get("UNAST_COMM_LIB"))       # tests: csrc/comm.cpp binds another library with RCCL's entry points (tests/native/fake_rccl.cpp)
+    if not config.NATIVE_COMM or not torch.cuda.is_available() or (dist.get_backend() != "nccl" and not shim):
         return 0
     import ctypes
     from ._lib import lib
@@ -81,10 +83,17 @@ def native_comm():
         ids[0] = bytes(buf) if buf is not None else b""
     dist.broadcast_object_list(ids, src=0)
     if len(ids[0]) != 128:
-        return 0
+        return 0                                         # (rank 0's verdict, broadcast: every rank returns here together)
+    # From here on a rank that fails locally must STILL take part in the agreement below: a rank that returned early would leave the
+    # others blocked in the probe collective / the MIN all-reduce for good.  Two rounds, both over the launcher's process group:
+    # (1) did every rank get a communicator?  Only then (2) the probe collective on it, and the verdict on its result.
     b = ctypes.create_string_buffer(ids[0], 128)
     h = L.unast_comm_init(ctypes.addressof(b), rank, world)
-    if not h:
+    flag = torch.tensor([1.0 if h else 0.0], device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if float(flag) < 1.0:
+        if h:
+            L.unast_comm_destroy(h)
         return 0
     probe = torch.ones(256, dtype=torch.float32, device="cuda")
     ok = L.unast_allreduce(h, probe.data_ptr(), probe.numel(), ops._stream()) == 0
