@@ -276,6 +276,33 @@ def test_lru_keeps_the_hot_shape_while_cold_ones_pass_through(monkeypatch):
     assert all(np.isfinite([float(x) for x in v]).all() for v in losses.values())
 
 
+def test_loss_workspaces_are_zero_whenever_they_are_handed_out(monkeypatch):
+    """config.DEBUG_WORKSPACES: every loss-workspace slot (train._loss_ws ring, ops.masked_mse per stream) is checked to be zero on entry
+    -- the invariant the zero-on-exit kernels rest on -- over 70 sub-step calls (the 64-slot ring wraps) and masked_mse on two streams."""
+    from unast_amd import config, train, ops
+    from unast_amd.portable import synth_batch
+    monkeypatch.setattr(config, "DEBUG_WORKSPACES", True)
+    args, model, opt = build(2, 1e-3)[:3]
+    batch = tuple(torch.from_numpy(x) for x in synth_batch(2, 12, 24, seed=1, ragged=True))
+    losses = defaultdict(list)
+    for i in range(12):
+        train.train_step(losses, model, opt, None, dict(unsup=[batch], sup=[batch], disc=[batch], cm=[]), i, args)
+    g = torch.Generator().manual_seed(0)
+    gold, pred = torch.rand(5, 7, 80, generator=g).to(D), torch.rand(5, 7, 80, generator=g).to(D)
+    mask = (torch.rand(5, 7, 80, generator=g) > 0.3).float().to(D)
+    ref = float(((gold - pred) ** 2 * mask).sum() / mask.sum())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    for _ in range(3):
+        a = train.masked_mse(gold, pred, mask)
+        with torch.cuda.stream(side):
+            b = train.masked_mse(gold, pred, mask)
+    torch.cuda.synchronize()
+    assert abs(float(a) - ref) < 1e-5 * ref and abs(float(b) - ref) < 1e-5 * ref
+    with pytest.raises(RuntimeError, match="forward-only"):
+        train.masked_mse(gold, pred.clone().requires_grad_(True), mask)
+
+
 def test_loss_workspace_ring_wraps_without_harm():
     """Thirty eager steps: the loss kernels' zero-on-entry workspaces come from a 64-slot ring shared by the text and the speech loss, so
     slots change hands between the two kernels after about ten steps (the text loss's saved weight sum must not be taken for the speech

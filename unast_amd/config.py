@@ -103,3 +103,7 @@ ENC_SKIP_PAD_GRADS = os.environ.get("UNAST_ENC_SKIP_PAD_GRADS", "0") == "1"
 # random length up to this many microseconds, which shifts the streams against each other; results must not change (tests/test_gpu_streams.py).
 STREAM_JITTER = int(os.environ.get("UNAST_STREAM_JITTER", "0"))
 STREAM_JITTER_SEED = int(os.environ.get("UNAST_STREAM_JITTER_SEED", "0"))
+
+# Test / debugging aid: loss kernels keep zero-on-entry / zero-on-exit workspaces (ops.masked_mse, train._loss_ws); 1 = check a workspace is
+# zero when it is handed out (one host synchronisation per call).
+DEBUG_WORKSPACES = os.environ.get("UNAST_DEBUG_WORKSPACES", "0") == "1"

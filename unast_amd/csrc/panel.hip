@@ -19,6 +19,7 @@
 // here -- z, y, mean and rstd are written by the GEMM and the stand-alone LayerNorm launch disappears (post-LN sub-layers,
 // SURVEY.md Appendix A).
 #include "common.h"
+#include <algorithm>
 #include "../../include/unast_hip.h"
 #include <type_traits>
 
@@ -845,6 +846,10 @@ extern "C" int unast_panel_gemm(const float* A, int lda, const void* w_planes, i
                                 const float* ln_gamma, const float* ln_beta, float* Y, int ldy, float* mean, float* rstd, float eps,
                                 void* gate_bits, int rows_per_wg, hipStream_t stream) {
     UNAST_REQUIRE(A && w_planes && C && M > 0 && N > 0 && K >= 4, "unast_panel_gemm: bad arguments");
+    {   // A, C, R, Y are addressed through buffer descriptors with 32-bit byte offsets: past 2 GiB loads would read zeros and stores be dropped
+        const size_t ld_max = (size_t)std::max(std::max(lda, ldc), std::max(R ? ldr : 0, Y ? ldy : 0));
+        UNAST_REQUIRE(((size_t)M + 127) / 128 * 128 * ld_max * 4 < (size_t)0x7FFFFFF0u, "unast_panel_gemm: operand of %d rows x %zu floats exceeds the 2 GiB a buffer descriptor addresses (use unast_gemm)", M, ld_max);
+    }
     if (K > 256) {
         // K-streamed form: output-stationary 128 x 256 tiles
         UNAST_REQUIRE((K & 63) == 0 && (N & 255) == 0 && (lda & 3) == 0 && (ldc & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)C) | ((uintptr_t)w_planes)) & 15) == 0,

@@ -124,6 +124,8 @@ def _panel_ok(M, K, *tensors, N=None):
     for t in tensors:
         if t is not None and (t.stride(-1) != 1 or t.data_ptr() % 16 or t.stride(0) % 4):
             return False
+        if t is not None and (M + 127) // 128 * 128 * t.stride(0) * 4 >= 0x7FFFFFF0:      # 32-bit buffer offsets (unast_panel_gemm refuses it too)
+            return False
     return True
 
 
@@ -688,12 +690,16 @@ _MSE_WS = {}
 
 
 def masked_mse(gold, pred, mask):
-    """src/train.py:100-103 on flat fp32 tensors; returns a device scalar."""
+    """src/train.py:100-103 on flat fp32 tensors; returns a device scalar.  The kernel's workspace (two sums and an arrival counter,
+    zero on entry, left zero) is one per (device, stream): calls on different streams may overlap, calls on one stream are ordered."""
     dev = gold.device
-    ws = _MSE_WS.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _MSE_WS.get(key)
     if ws is None:
-        ws = _MSE_WS[dev] = torch.zeros(3, dtype=torch.float64, device=dev)
-        torch.cuda.synchronize(dev)                  # filled once, used from any stream afterwards: nobody may run ahead of the fill
+        ws = _MSE_WS[key] = torch.zeros(3, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)                  # filled once: nobody may run ahead of the fill
+    if config.DEBUG_WORKSPACES and bool((ws != 0).any()):
+        raise RuntimeError("masked_mse: workspace not zero on entry (an earlier call on this stream died midway?)")
     out = torch.empty((), dtype=torch.float32, device=dev)
     check(lib().unast_masked_mse(_p(gold), _p(pred), _p(mask), gold.numel(), _p(ws), _p(out), _stream()), "unast_masked_mse")
     return out

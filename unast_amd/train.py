@@ -136,6 +136,11 @@ def _loss_ws(dev):
         torch.cuda.synchronize(dev)
     i = ring[1]
     ring[1] = (i + 1) % 64
+    from . import config
+    if config.DEBUG_WORKSPACES and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize(dev)
+        if bool((ring[0][i][:4] != 0).any()):
+            raise RuntimeError("loss workspace slot %d is not zero on entry: %r (a loss kernel of an earlier call died midway, or two calls share a slot)" % (i, ring[0][i].tolist()))
     return ring[0][i]
 
 
@@ -170,6 +175,9 @@ def masked_mse(gold_mel, pred_mel, mel_mask):
     """src/train.py:100-103: sum((gold - pred)^2 * mask) / sum(mask), a device scalar.  Forward only: the train step's two masked MSEs
     and the stop loss come out of one fused kernel with their gradients (speech_loss below); this entry serves evaluation code that
     calls it directly."""
+    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (gold_mel, pred_mel)):
+        raise RuntimeError("masked_mse is forward-only on this path (no gradient would reach its inputs): differentiate through speech_loss, "
+                           "or call it under torch.no_grad() / on detached tensors")
     gold, pred, mask = (t.detach().reshape(-1).to(torch.float32).contiguous() for t in (gold_mel, pred_mel, mel_mask))
     if not (gold.numel() == pred.numel() == mask.numel()):
         raise ValueError("masked_mse: gold, pred and mask must have the same number of elements")
