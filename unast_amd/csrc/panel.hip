@@ -251,9 +251,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void panel_kernel(const PanelParam
     // output (WBITS); the input-gradient GEMM through linear2 reads them with SCALAR loads (RGATE) instead of streaming the hidden
     // activation as a gate operand (105 MB per launch at config 3, and vector loads inside the ring's loop).
     const int ntile_n = (p.N + 15) >> 4, ntile_m = (p.M + 15) >> 4;
-    // The buffer holds whole 128-row panels (ceil128(M) rows): a partial panel's rows beyond M get their words written too.  (Relying on the
-    // descriptor's range check to drop them did not work for these 8-byte stores -- tools/panel_guard.py found every out-of-range word
-    // written behind the buffer -- although the same check does drop the 16-byte C stores of rows >= M, which tests/test_gpu_panel.py pins.)
+    // The buffer holds whole 128-row panels (ceil128(M) rows): a partial panel's rows beyond M get their words written too, and num_records
+    // below covers exactly that.  (Round 3 first allocated the buffer for M rows while this descriptor already spanned whole panels: the
+    // words of rows >= M were IN range of the descriptor and landed behind the allocation -- the fault of gpurun_out/r3/tpanel2.log.  The
+    // note that stood here blamed the hardware ("8-byte buffer stores beyond num_records are not dropped"); tools/buffer_oob_probe.cpp shows
+    // gfx950 drops 4-, 8- and 16-byte stores beyond num_records alike, byte-exactly, with the base in the vector or the scalar offset.)
     const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gate_bits, 0, ((p.M + 127) >> 7) * 8 * ntile_n * 32, 0x00020000);
     auto epilogue_fast = [&](int cg, f32x4 (&ac)[RT][2], auto act_t, auto drop_t, auto split_t, auto wbits_t, auto rgate_t) {
         constexpr bool ACT = decltype(act_t)::value, DROP = decltype(drop_t)::value, SPLIT = decltype(split_t)::value;
