@@ -276,6 +276,54 @@ def test_lru_keeps_the_hot_shape_while_cold_ones_pass_through(monkeypatch):
     assert all(np.isfinite([float(x) for x in v]).all() for v in losses.values())
 
 
+def test_mutual_waits_between_side_streams_are_refused_inside_a_capture():
+    """ROCm 7.2's hipStreamEndCapture crashes (inside the runtime) when two streams forked from the capture's origin wait on each other
+    (A waits for B after B waited for A: tools/debug_capture2.py T1).  The package never builds that topology and its wait helper refuses
+    it with a Python error while the capture is still open -- exactly that topology here, through engine.wait; one-way waits and waits
+    through the origin stay legal, and outside a capture nothing is checked."""
+    from unast_amd import engine
+    from unast_amd.inference import _capture
+    x = torch.zeros(1 << 16, device=D)
+    A, B = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def legal():
+        O = torch.cuda.current_stream()
+        engine.wait(A, O); engine.wait(B, O)
+        with torch.cuda.stream(A):
+            x.add_(1.0)
+        engine.wait(B, A)                       # one way: fine
+        with torch.cuda.stream(B):
+            x.add_(1.0)
+        engine.wait(O, B); engine.wait(A, O)    # ... and back through the origin: fine
+        with torch.cuda.stream(A):
+            x.add_(1.0)
+        engine.wait(O, A)
+    g = _capture(legal)
+    x.zero_(); g.replay(); torch.cuda.synchronize()
+    assert float(x[0]) == 3.0
+
+    def cyclic():
+        O = torch.cuda.current_stream()
+        engine.wait(A, O); engine.wait(B, O)
+        with torch.cuda.stream(A):
+            x.add_(1.0)
+        engine.wait(B, A)
+        with torch.cuda.stream(B):
+            x.add_(1.0)
+        try:
+            engine.wait(A, B)                   # B has waited for A: refused
+        finally:
+            engine.wait(O, A); engine.wait(O, B)
+    with pytest.raises(RuntimeError, match="may not wait on each other"):
+        _capture(cyclic)
+    torch.cuda.synchronize()
+    engine.wait(A, B); engine.wait(B, A)        # outside a capture: ordinary waits
+    torch.cuda.synchronize()
+    g2 = _capture(legal)                        # and the next capture works
+    x.zero_(); g2.replay(); torch.cuda.synchronize()
+    assert float(x[0]) == 3.0
+
+
 def test_loss_workspaces_are_zero_whenever_they_are_handed_out(monkeypatch):
     """config.DEBUG_WORKSPACES: every loss-workspace slot (train._loss_ws ring, ops.masked_mse per stream) is checked to be zero on entry
     -- the invariant the zero-on-exit kernels rest on -- over 70 sub-step calls (the 64-slot ring wraps) and masked_mse on two streams."""

@@ -154,7 +154,7 @@ def _issue_stream():
     cur = torch.cuda.current_stream()
     w = engine._wgrad_stream_of_current() if engine._Streams.enabled or engine._Streams.used else None
     if w is not None and w != cur:
-        w.wait_stream(cur)
+        engine.wait(w, cur)
         return w
     return cur
 
@@ -224,7 +224,7 @@ def _issue(store, label, rng, overlap):
             if name.endswith("_w"):
                 c = engine._side(name)
                 if c != s:
-                    s.wait_stream(c)
+                    engine.wait(s, c)
         with torch.cuda.stream(s):
             # One communicator, one collective at a time: the buckets are issued from several streams (the companions of the text and of
             # the speech side, the discriminator's), and two collectives of one RCCL communicator that run concurrently -- or in a
@@ -254,7 +254,7 @@ def _issue(store, label, rng, overlap):
             if name.endswith("_w"):
                 c = engine._side(name)
                 if c != s:
-                    s.wait_stream(c)
+                    engine.wait(s, c)
         with torch.cuda.stream(s):
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)   # RCCL: runs behind `s` on the group's own stream
         _State.pending.append(work)

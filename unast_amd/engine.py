@@ -98,7 +98,7 @@ def join_wgrad_streams():
     cur = torch.cuda.current_stream()
     for name in list(_Streams.used):
         if name.endswith("_w"):
-            cur.wait_stream(_side(name))
+            wait(cur, _side(name))
 
 
 def stream_of(name):
@@ -121,9 +121,45 @@ def join_streams():
     for name in _Streams.used:
         s = _side(name)
         if s != cur:
-            cur.wait_stream(s)
+            wait(cur, s)
     if not _Streams.enabled:
         _Streams.used.clear()
+
+
+class _CaptureWaits:
+    """Waits between streams placed by this package while a HIP graph is being captured.  ROCm 7.2's hipStreamEndCapture dies (a
+    segmentation fault inside the runtime, tools/debug_capture2.py T1 / T6 / T10) when two streams that are both forked from the capture's
+    origin wait on EACH OTHER -- A waits for B after B has waited for A; one-way waits (T9) and waits through the origin (T3) are fine.
+    The cause inside the runtime is not known; the package therefore never builds that topology (on_stream hands tensors side -> origin
+    -> side, _ViaOrigin makes autograd do the same, ddp._issue leaves marker nodes without events), and every explicit wait goes through
+    `wait()` below, which REFUSES the second half of such a pair with a Python error instead of letting the process die in EndCapture."""
+    origin = None        # the capture's origin stream (inference._capture)
+    edges = set()        # (waiter stream, source stream) pairs of the open capture
+
+
+def capture_begins(origin):
+    _CaptureWaits.origin = origin
+    _CaptureWaits.edges = set()
+
+
+def capture_ends():
+    _CaptureWaits.origin = None
+    _CaptureWaits.edges = set()
+
+
+def wait(waiter, source_stream, event=None):
+    """`waiter` waits for `event` (recorded on `source_stream`) or, without one, for everything enqueued on `source_stream`."""
+    o = _CaptureWaits.origin
+    if o is not None and waiter != o and source_stream != o and waiter != source_stream:
+        a, b = waiter.cuda_stream, source_stream.cuda_stream
+        if (b, a) in _CaptureWaits.edges:
+            raise RuntimeError("inside a HIP-graph capture two side streams may not wait on each other (stream %#x already waited for %#x): "
+                               "hipStreamEndCapture of ROCm 7.2 crashes on that topology -- hand over through the capture's origin stream" % (b, a))
+        _CaptureWaits.edges.add((a, b))
+    if event is not None:
+        waiter.wait_event(event)
+    else:
+        waiter.wait_stream(source_stream)
 
 
 import os as _os
@@ -170,7 +206,7 @@ def on_stream(name):
                     cross.add(id(t))
                     if id(src[1]) not in waited:
                         # only the call that produced this input, not its whole stream; while capturing, through the caller's stream
-                        (cur if via_origin else s).wait_event(src[1])
+                        wait(cur if via_origin else s, _side(src[0]), src[1])
                         waited.add(id(src[1]))
                 t.record_stream(s)
             if via_origin and cross:
@@ -182,7 +218,7 @@ def on_stream(name):
                     return o
                 args = tuple(route(a) for a in args)
                 kw = {k: route(v) for k, v in kw.items()}
-            s.wait_stream(cur)
+            wait(s, cur)
             with torch.cuda.stream(s):
                 ops.jitter()                            # (test infrastructure, off by default: config.STREAM_JITTER)
                 if _Streams.trace is not None:          # diagnostic only (tools/stream_timeline.py): event pair around the call

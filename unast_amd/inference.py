@@ -111,13 +111,22 @@ def _capture(fn, pool=None, keep_graph=False):
         cs = _CAPTURE_STREAM[dev] = torch.cuda.Stream()
     cur = torch.cuda.current_stream()
     graph = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()      # keep_graph: the hipGraph_t stays readable
+    from . import engine
     cs.wait_stream(cur)
     with torch.cuda.stream(cs):
         graph.capture_begin(**({"pool": pool} if pool is not None else {}))
+        engine.capture_begins(cs)            # explicit waits between forked streams are checked from here on (engine._CaptureWaits)
         try:
             fn()
-        finally:
-            graph.capture_end()
+        except BaseException:
+            engine.capture_ends()
+            try:
+                graph.capture_end()            # close the capture so that the stream is usable again; the error below is the one to report
+            except Exception:
+                pass
+            raise
+        engine.capture_ends()
+        graph.capture_end()
     cur.wait_stream(cs)
     return graph
 

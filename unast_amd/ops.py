@@ -223,7 +223,8 @@ def _on_wgrad_stream(launch, tokens, key, *operands):
             w = None
     if w is None:
         return launch()
-    w.wait_stream(torch.cuda.current_stream())
+    from . import engine
+    engine.wait(w, torch.cuda.current_stream())
     for t in operands:
         if t is not None:
             t.record_stream(w)
@@ -327,7 +328,8 @@ def _launch_group(chunk, offload):
         sys.modules[__name__].wgrad_group(shapes, n, ptr, ws_n, chunk[0][0].device)       # looked up at call time: bench.py wraps it with HIP events
     if offload:
         w = WGRAD_SIDE()
-        w.wait_stream(torch.cuda.current_stream())
+        from . import engine
+        engine.wait(w, torch.cuda.current_stream())
         for t in operands:
             t.record_stream(w)
         with torch.cuda.stream(w):
