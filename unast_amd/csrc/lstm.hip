@@ -17,57 +17,74 @@ __device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn
 #define FCH 16            // forward: timesteps of input projections held in registers per chunk
 #define BCH 8             // backward: timesteps of saved state held in registers per chunk
 
+// Sums / exchanges over the four 16-lane rows of a wave by gfx950's permlane swaps (no LDS crossbar, no barrier).  Fed the same register
+// twice, v_permlane16_swap returns (value of the pair's EVEN-row lane, value of its ODD-row lane) in every lane of a {l, l ^ 16} pair, and
+// v_permlane32_swap (value of the lower-half lane, value of the upper-half lane) of a {l, l ^ 32} pair.
+__device__ __forceinline__ void swap16(float v, float& even_row, float& odd_row) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    even_row = __uint_as_float(a[0]); odd_row = __uint_as_float(a[1]);
+}
+__device__ __forceinline__ void swap32(float v, float& lower, float& upper) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    lower = __uint_as_float(a[0]); upper = __uint_as_float(a[1]);
+}
+
 // xproj [Bd,T,ndir*LG] (no bias), y [Bd,T,ndir*LH], gates [Bd,T,ndir,LG], cs [Bd,T,ndir,LH], hprev [Bd,T,ndir,LH], hfinal [Bd, ndir*LH].
 // y and hprev of the padded steps t >= len are written as zeros here (they are GEMM operands of the next layer / of the weight
 // gradients over all Bd*T rows): the caller allocates them uninitialised -- pre-zeroing them with a fill launch each was 26 MB of
 // memset per tensor and call at config 3.
 //
-// One barrier per timestep: thread j (wave w = j>>6 owns gate type i/f/g/o) computes its gate pre-activation from the
-// wave-private copy of h, publishes the activated gate in a double-buffered LDS array, and after the barrier EVERY wave
-// redundantly performs the cell update of hidden unit j&63 and refreshes its private h copy (no second barrier).
-// Global latency is taken off the per-step critical path: each thread keeps the projections of the current chunk of
-// FCH steps in registers while the next chunk's loads are in flight (one vmcnt wait per chunk, not per step).
+// Round 4 layout: the four gates of a hidden unit live in ONE wave.  Wave w owns units [16 w, 16 w + 16); lane l = 16 q + c computes gate
+// q (i, f, g, o) of unit 16 w + c, i.e. row 64 q + 16 w + c of W_hh (64 floats in VGPRs).  After the activation three permlane swaps hand
+// every lane the other three gates of its unit, the cell update happens in place (four times redundantly), and the only thing that
+// crosses waves is h: 16 values per wave into a double-buffered LDS vector, ONE barrier per step, one LDS round trip on the step's
+// dependent chain (the round-1..3 form published the activated gates through LDS, met at the barrier, read four gates back, and then
+// paid a second write -> read hop for its wave-private copy of h: ~1 050 cycles per step, of which the two hops were about a third).
+// Global latency stays off the chain: the projections of FCH steps are register-resident while the next chunk's loads are in flight.
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ xproj, const float* __restrict__ whh, const float* __restrict__ b_ih,
                                                        const float* __restrict__ b_hh, const int* __restrict__ lens, float* __restrict__ y,
                                                        float* __restrict__ gates, float* __restrict__ cs, float* __restrict__ hprev,
                                                        float* __restrict__ hfinal, int T, int ndir, size_t whh_dir_stride, size_t bias_dir_stride) {
-    __shared__ __attribute__((aligned(16))) float h_lds[4][LH];       // one private copy per wave
-    __shared__ float g_lds[2][LG];
+    __shared__ __attribute__((aligned(16))) float h_lds[2][LH];
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
-    const int wave = j >> 6, u = j & 63;
+    const int wave = j >> 6, lane = j & 63, q = lane >> 4;
+    const int u = 16 * wave + (lane & 15);             // hidden unit of this lane
+    const int row = q * LH + u;                        // its gate row
     const int len = lens[b];
-    f32x2 w[LH / 2];                       // row j of W_hh as register pairs: the dot product below runs on v_pk_fma_f32
-    const float* wr = whh + dir * whh_dir_stride + (size_t)j * LH;
+    f32x2 w[LH / 2];                       // row `row` of W_hh as register pairs: the dot product below runs on v_pk_fma_f32
+    const float* wr = whh + dir * whh_dir_stride + (size_t)row * LH;
 #pragma unroll
     for (int k = 0; k < LH; k += 4) {
         float4 v = *reinterpret_cast<const float4*>(wr + k);
         w[k / 2] = (f32x2){v.x, v.y}; w[k / 2 + 1] = (f32x2){v.z, v.w};
     }
-    const float bias = b_ih[dir * bias_dir_stride + j] + b_hh[dir * bias_dir_stride + j];
-    h_lds[wave][u] = 0.f;
-    for (int t = max(len, 0) + wave; t < T; t += 4) {                // padded steps: wave w clears every 4th one
-        y[((size_t)b * T + t) * ((size_t)ndir * LH) + dir * LH + u] = 0.f;
-        hprev[(((size_t)b * T + t) * ndir + dir) * LH + u] = 0.f;
+    const float bias = b_ih[dir * bias_dir_stride + row] + b_hh[dir * bias_dir_stride + row];
+    if (j < LH) h_lds[0][j] = 0.f;
+    for (int t = max(len, 0) + wave; t < T; t += 4) {                // padded steps: wave w clears every 4th one (lane = unit here)
+        y[((size_t)b * T + t) * ((size_t)ndir * LH) + dir * LH + lane] = 0.f;
+        hprev[(((size_t)b * T + t) * ndir + dir) * LH + lane] = 0.f;
     }
     if (len <= 0) {                                                  // (uniform) empty sequence: final state = initial state
-        if (wave == 0) hfinal[(size_t)b * (ndir * LH) + dir * LH + u] = 0.f;
+        if (wave == 0) hfinal[(size_t)b * (ndir * LH) + dir * LH + lane] = 0.f;
         return;
     }
+    __syncthreads();
     float c = 0.f, h = 0.f;
     const size_t xs = (size_t)ndir * LG;
-    const float* xp = xproj + (size_t)b * T * xs + (size_t)dir * LG + j;
+    const float* xp = xproj + (size_t)b * T * xs + (size_t)dir * LG + row;
     const int tstep = dir ? -1 : 1;
     const int t0 = dir ? len - 1 : 0;
     // Output pointers of the first step, advanced by one time step per iteration (the 64-bit row arithmetic per step was
     // a fifth of the step's instructions, all of them on its dependent chain).
     const size_t row0 = ((size_t)b * T + t0) * ndir + dir;
-    float* gp = gates + row0 * LG + j;
+    float* gp = gates + row0 * LG + row;
     float* hp = hprev + row0 * LH + u;
     float* cp = cs + row0 * LH + u;
     float* yp = y + ((size_t)b * T + t0) * ((size_t)ndir * LH) + dir * LH + u;
     const ptrdiff_t g_inc = (ptrdiff_t)tstep * ndir * LG, h_inc = (ptrdiff_t)tstep * ndir * LH, y_inc = (ptrdiff_t)tstep * ndir * LH;
-    // sigmoid(x) = 1 / (1 + exp(-x)), tanh(x) = 2 / (1 + exp(-2x)) - 1: one branch-free form with wave-uniform constants (wave 2 = g)
-    const float act_m = (wave == 2) ? -2.f : -1.f, act_s = (wave == 2) ? 2.f : 1.f, act_o = (wave == 2) ? -1.f : 0.f;
+    // sigmoid(x) = 1 / (1 + exp(-x)), tanh(x) = 2 / (1 + exp(-2x)) - 1: one branch-free form with per-lane constants (lane row 2 = g)
+    const float act_m = (q == 2) ? -2.f : -1.f, act_s = (q == 2) ? 2.f : 1.f, act_o = (q == 2) ? -1.f : 0.f;
+    const bool writer = q == 0;                                      // one lane row per wave stores the unit's state
     float xc[FCH], xn[FCH];
     auto load_chunk = [&](int s0, float (&x)[FCH]) {
 #pragma unroll
@@ -84,11 +101,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < FCH; ++i) {
             if (s0 + i < len) {                                      // (uniform; a guard, not a break, so that the chunk unrolls and xc[i] is a register)
+                const float* hl = h_lds[i & 1];                      // (FCH is even: the step's parity is i & 1)
                 f32x2 a0 = {xc[i] + bias, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};     // four independent chains of 8 packed FMAs
 #pragma unroll
                 for (int k = 0; k < LH; k += 8) {
-                    const float4 hv0 = *reinterpret_cast<const float4*>(&h_lds[wave][k]);
-                    const float4 hv1 = *reinterpret_cast<const float4*>(&h_lds[wave][k + 4]);
+                    const float4 hv0 = *reinterpret_cast<const float4*>(&hl[k]);
+                    const float4 hv1 = *reinterpret_cast<const float4*>(&hl[k + 4]);
                     a0 = __builtin_elementwise_fma(w[k / 2], (f32x2){hv0.x, hv0.y}, a0);
                     a1 = __builtin_elementwise_fma(w[k / 2 + 1], (f32x2){hv0.z, hv0.w}, a1);
                     a2 = __builtin_elementwise_fma(w[k / 2 + 2], (f32x2){hv1.x, hv1.y}, a2);
@@ -96,39 +114,41 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
                 }
                 const float pre = ((a0[0] + a0[1]) + (a1[0] + a1[1])) + ((a2[0] + a2[1]) + (a3[0] + a3[1]));
                 const float act = __builtin_fmaf(__builtin_amdgcn_rcpf(1.f + __expf(act_m * pre)), act_s, act_o);
-                float* gl = g_lds[i & 1];
-                gl[j] = act;
                 *gp = act;
-                __syncthreads();
-                const float ig = gl[u], fg = gl[LH + u], gg = gl[2 * LH + u], og = gl[3 * LH + u];
-                if (wave == 0) *hp = h;
+                float e16, o16, ig, gg, fg, og;
+                swap16(act, e16, o16);                               // rows (0, 1): (i, f); rows (2, 3): (g, o)
+                swap32(e16, ig, gg);
+                swap32(o16, fg, og);
+                if (writer) *hp = h;
                 c = fg * c + ig * gg;
                 h = og * tanhf_(c);
-                if (wave == 0) { *cp = c; *yp = h; }
-                h_lds[wave][u] = h;           // same-wave LDS write -> read ordering: no barrier needed
+                if (writer) { *cp = c; *yp = h; h_lds[(i + 1) & 1][u] = h; }
                 gp += g_inc; hp += h_inc; cp += h_inc; yp += y_inc;
+                __syncthreads();
             }
         }
     }
-    if (wave == 0) hfinal[(size_t)b * (ndir * LH) + dir * LH + u] = h;
+    if (writer) hfinal[(size_t)b * (ndir * LH) + dir * LH + u] = h;
 }
 
 // Backward through time.  dy [Bd,T,ndir*LH] (may be null), dhfinal [Bd,ndir*LH] (may be null),
 // dgates [Bd,T,ndir,LG]: receives d(pre-activation gates) for the valid steps and zeros for the padded ones (t >= len).
-// One barrier per step: every wave redundantly forms the four gate gradients of unit k = lane (from the shared dh),
-// keeps them in a wave-private LDS copy, computes its quarter (gate rows 64*wave..) of dh_prev = dg . W_hh, and after
-// the barrier every wave sums the four partials.  Saved gates / cell states / dy of BCH steps are register-resident
-// while the next chunk's loads are in flight.
+// Same ownership as the forward (round 4): wave w owns units [16 w, 16 w + 16), lane l = 16 q + c.  Every lane forms the cell's gradients
+// of ITS unit from registers (saved gates / cell states / dy of BCH steps are register-resident while the next chunk's loads are in
+// flight), keeps the one of gate q, and publishes it in a double-buffered LDS vector of the 256 gate gradients -- ONE barrier --; then
+// lane (q, c) multiplies the 64 gradients of gate type q by column 16 w + c of that gate's W_hh block and two permlane swaps sum the four
+// gate types: dh of the previous step, in every lane of the unit, without a second trip through LDS (the earlier form split the gate
+// rows over the waves, wrote its partial sums to LDS and summed them after the barrier: two hops per step).
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dhfinal, const float* __restrict__ whh,
                                                        const float* __restrict__ gates, const float* __restrict__ cs, const int* __restrict__ lens,
                                                        float* __restrict__ dgates, int T, int ndir, size_t whh_dir_stride) {
-    __shared__ __attribute__((aligned(16))) float dg_lds[4][LG];      // wave-private copies
-    __shared__ float part_lds[2][4][LH];
+    __shared__ __attribute__((aligned(16))) float dg_lds[2][LG];
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
     const int len = lens[b];
-    const int k = j & 63, part = j >> 6;
-    f32x2 wt[LH / 2];                   // wt[q] = {W_hh[64*part + 2q][k], W_hh[64*part + 2q+1][k]}: register pairs for v_pk_fma_f32
-    const float* wr = whh + dir * whh_dir_stride + (size_t)(part * LH) * LH + k;
+    const int wave = j >> 6, lane = j & 63, q = lane >> 4;
+    const int k = 16 * wave + (lane & 15);          // this lane's hidden unit
+    f32x2 wt[LH / 2];                   // wt[i] = {W_hh[64 q + 2i][k], W_hh[64 q + 2i + 1][k]}: register pairs for v_pk_fma_f32
+    const float* wr = whh + dir * whh_dir_stride + (size_t)(q * LH) * LH + k;
 #pragma unroll
     for (int i = 0; i < LH; i += 2) wt[i / 2] = (f32x2){wr[(size_t)i * LH], wr[(size_t)(i + 1) * LH]};
     float dh = 0.f, dc = 0.f;
@@ -142,9 +162,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         for (int i = 0; i < BCH; ++i) {
             const int r = min(r0 + i, len - 1);
             const int t = t0 + r * tstep;
-            const size_t row = ((size_t)b * T + t) * ndir + dir;
-            v[i][0] = gates[row * LG + k]; v[i][1] = gates[row * LG + LH + k]; v[i][2] = gates[row * LG + 2 * LH + k]; v[i][3] = gates[row * LG + 3 * LH + k];
-            v[i][4] = cs[row * LH + k];
+            const size_t rw = ((size_t)b * T + t) * ndir + dir;
+            v[i][0] = gates[rw * LG + k]; v[i][1] = gates[rw * LG + LH + k]; v[i][2] = gates[rw * LG + 2 * LH + k]; v[i][3] = gates[rw * LG + 3 * LH + k];
+            v[i][4] = cs[rw * LH + k];
             const int rp = min(r + 1, len - 1);             // previous forward step (clamped; masked below for the first step)
             v[i][5] = cs[(((size_t)b * T + (t0 + rp * tstep)) * ndir + dir) * LH + k];
             v[i][6] = dy ? dy[((size_t)b * T + t) * (ndir * LH) + dir * LH + k] : 0.f;
@@ -152,14 +172,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     };
     for (int t = max(len, 0); t < T; ++t) dgates[(((size_t)b * T + t) * ndir + dir) * LG + j] = 0.f;       // padded steps: 1 KB per step
     if (len <= 0) return;                                   // (uniform)
-    float* dgr = dgates + (((size_t)b * T + t0) * ndir + dir) * LG + k;        // advanced by one time step per iteration
+    float* dgr = dgates + (((size_t)b * T + t0) * ndir + dir) * LG + q * LH + k;        // advanced by one time step per iteration
     const ptrdiff_t dg_inc = (ptrdiff_t)tstep * ndir * LG;
     load_chunk(0, vn);
     for (int r0 = 0; r0 < len; r0 += BCH) {
 #pragma unroll
         for (int i = 0; i < BCH; ++i)
 #pragma unroll
-            for (int q = 0; q < 7; ++q) vc[i][q] = vn[i][q];
+            for (int qq = 0; qq < 7; ++qq) vc[i][qq] = vn[i][qq];
         if (r0 + BCH < len) load_chunk(r0 + BCH, vn);
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
@@ -175,24 +195,27 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
             const float d_f = dct * cprev * fg * (1.f - fg);
             const float d_g = dct * ig * (1.f - gg * gg);
             dc = dct * fg;
-            float* dgw = dg_lds[part];
-            dgw[k] = d_i; dgw[LH + k] = d_f; dgw[2 * LH + k] = d_g; dgw[3 * LH + k] = d_o;
-            if (part == 0) { dgr[0] = d_i; dgr[LH] = d_f; dgr[2 * LH] = d_g; dgr[3 * LH] = d_o; }
+            const float mine = q == 0 ? d_i : q == 1 ? d_f : q == 2 ? d_g : d_o;
+            float* dgw = dg_lds[i & 1];                     // (BCH is even: the step's parity is i & 1)
+            dgw[q * LH + k] = mine;
+            *dgr = mine;
             dgr += dg_inc;
+            __syncthreads();
             f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};      // four independent chains of 8 packed FMAs
 #pragma unroll
             for (int ii = 0; ii < LH; ii += 8) {
-                const float4 dv0 = *reinterpret_cast<const float4*>(&dgw[part * LH + ii]);      // written by this wave just above
-                const float4 dv1 = *reinterpret_cast<const float4*>(&dgw[part * LH + ii + 4]);
+                const float4 dv0 = *reinterpret_cast<const float4*>(&dgw[q * LH + ii]);
+                const float4 dv1 = *reinterpret_cast<const float4*>(&dgw[q * LH + ii + 4]);
                 a0 = __builtin_elementwise_fma(wt[ii / 2], (f32x2){dv0.x, dv0.y}, a0);
                 a1 = __builtin_elementwise_fma(wt[ii / 2 + 1], (f32x2){dv0.z, dv0.w}, a1);
                 a2 = __builtin_elementwise_fma(wt[ii / 2 + 2], (f32x2){dv1.x, dv1.y}, a2);
                 a3 = __builtin_elementwise_fma(wt[ii / 2 + 3], (f32x2){dv1.z, dv1.w}, a3);
             }
-            float (*pl)[LH] = part_lds[i & 1];
-            pl[part][k] = ((a0[0] + a0[1]) + (a1[0] + a1[1])) + ((a2[0] + a2[1]) + (a3[0] + a3[1]));
-            __syncthreads();
-            dh = (pl[0][k] + pl[1][k]) + (pl[2][k] + pl[3][k]);
+            const float part = ((a0[0] + a0[1]) + (a1[0] + a1[1])) + ((a2[0] + a2[1]) + (a3[0] + a3[1]));
+            float e16, o16, lo, up;
+            swap16(part, e16, o16);
+            swap32(e16 + o16, lo, up);
+            dh = lo + up;                                   // (i + f) + (g + o): the same sum in every lane of the unit
             }
         }
     }
