@@ -67,8 +67,12 @@ def test_forward_matches_reference_golden(golden_dir, name, panel_rows):
     assert any(not torch.equal(v, model.state_dict()[k]) for k, v in bn_before.items()), "train-mode BN must update running stats"
 
 
+@pytest.mark.parametrize("joint", [False, True], ids=["substeps", "joint"])
 @pytest.mark.parametrize("name", ["step_b1_t40_m200_l4", "step_b4_t24_m64_l2", "step_b4_t24_m64_l4_lr0"])
-def test_full_step_matches_reference_golden(golden_dir, name, panel_rows):
+def test_full_step_matches_reference_golden(golden_dir, name, panel_rows, joint):
+    """joint: the generator phase as train.train_gen_joint_step (one forward and one backward over both sub-steps, encoders and
+    discriminator batched over the two) instead of train_ae_step + train_sp_step -- against the SAME reference fixture: seven losses,
+    per-tensor gradient norms, BatchNorm running statistics after two updates each, AdamW deltas."""
     from collections import defaultdict
     from unast_amd import train
     g, batch = load_case(golden_dir, name)
@@ -81,8 +85,12 @@ def test_full_step_matches_reference_golden(golden_dir, name, panel_rows):
     losses = defaultdict(list)
     model.train()
     train.freeze_model_parameters(model.discriminator)
-    train.train_ae_step(losses, model, batch, 0, 2, args)
-    train.train_sp_step(losses, model, batch, 0, 2, args)
+    if joint:
+        assert train.joint_generator_phase(args, batch, batch)
+        train.train_gen_joint_step(losses, model, batch, batch, 0, 2, args)
+    else:
+        train.train_ae_step(losses, model, batch, 0, 2, args)
+        train.train_sp_step(losses, model, batch, 0, 2, args)
     model.expose_grads()
     gn = np.array([params[n].grad.double().norm().item() if params[n].grad is not None else -1.0 for n in names])
     ref = g["gen_grad_norms"]

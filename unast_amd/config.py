@@ -107,3 +107,8 @@ STREAM_JITTER_SEED = int(os.environ.get("UNAST_STREAM_JITTER_SEED", "0"))
 # Test / debugging aid: loss kernels keep zero-on-entry / zero-on-exit workspaces (ops.masked_mse, train._loss_ws); 1 = check a workspace is
 # zero when it is handed out (one host synchronisation per call).
 DEBUG_WORKSPACES = os.environ.get("UNAST_DEBUG_WORKSPACES", "0") == "1"
+
+# The generator phase of an outer step with one auto-encoder and one supervised sub-step (ae_steps = sp_steps = 1, no cross-model sub-step,
+# both batches in one shape) as ONE forward and ONE backward (train.train_gen_joint_step): each encoder's stack runs once over both
+# sub-steps' batches, the frozen discriminator once over both sub-steps' encoder outputs.  0 = the two sub-steps one after the other.
+JOINT_GEN = os.environ.get("UNAST_JOINT_GEN", "1") != "0"

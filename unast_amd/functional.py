@@ -214,11 +214,12 @@ def decoder_stack(cx, tape, x, lens_q, mem, lens_k, pre, L, B, Tq, Tk, H, drop):
 # ---------------------------------------------------------------------------------------------------------------
 # Positional encoding (src/module.py:249-267; dropout fixed at 0.1)
 # ---------------------------------------------------------------------------------------------------------------
-def posenc(cx, tape, x, pe, T, gate=None):
+def posenc(cx, tape, x, pe, T, gate=None, out=None):
+    """out: an [N, Dm] row block of a larger buffer that receives the result (the two halves of a paired encoder call)."""
     N, Dm = x.v.shape
     p = cx.p(0.1)
     s = cx.stream()
-    y = _empty(N, Dm, like=x.v)
+    y = out if out is not None else _empty(N, Dm, like=x.v)
     scale = math.sqrt(Dm)
     ops.posenc_fwd(x.v, pe, y, T, scale, drop_p=p, seed=cx.seed, stream_id=s)
     out = Var(y)
@@ -325,16 +326,55 @@ def text_embed(cx, tape, ids, T, drop, noise, shift_sos):
     return out
 
 
-def text_encode(cx, tape, m, ids, lens, noise):
-    """TextTransformer.encode (src/network.py:427-444)."""
+def text_frontend(cx, tape, m, ids, noise, out=None):
+    """Embedding (+ noise_fn), the three conv + BatchNorm + ReLU stages and the positional encoding in front of the text encoder stack
+    (src/network.py:427-434): everything of TextTransformer.encode that sees the batch as a whole (BatchNorm statistics)."""
     B, T = ids.shape
     a = m.args
     x = text_embed(cx, tape, ids, T, a.t_pre_drop, noise, -1)
     pool = ZeroPool(3, cx.P["text_m.prenet.conv1.conv.weight"].shape[0], ids.device) if cx.training else None
     for i in (1, 2, 3):
         x = conv_bn_act(cx, tape, x, B, T, "text_m.prenet.conv%d." % i, "text_m.prenet.batch_norm%d." % i, 2, 1, a.t_pre_drop, m.buffers_dict, pool=pool)
-    x = posenc(cx, tape, x, m.pe, T)
+    return posenc(cx, tape, x, m.pe, T, out=out)
+
+
+def text_encode(cx, tape, m, ids, lens, noise):
+    """TextTransformer.encode (src/network.py:427-444)."""
+    B, T = ids.shape
+    a = m.args
+    x = text_frontend(cx, tape, m, ids, noise)
     return encoder_stack(cx, tape, x, lens, "text_m.encoder.transformer_encoder.layers.", a.num_layers, B, T, a.nhead, a.e_drop)
+
+
+def _stack_rows(cx, tape, halves, buf):
+    """Var over `buf` [2N, E], whose two row blocks the front ends of a paired encoder call have just written (posenc out=): the
+    gradient that comes back for the whole buffer is handed to the halves as row-block views (no copy either way)."""
+    x2 = Var(buf)
+    if tape is not None:
+        N = halves[0].v.shape[0]
+
+        def bwd():
+            if x2.g is None:
+                return
+            for i, h in enumerate(halves):
+                acc(h, x2.g[i * N:(i + 1) * N])
+        tape.record(bwd)                                # recorded after the halves' own closures => runs before them
+    return x2
+
+
+def text_encode_pair(cx, tape, m, ids_a, noise_a, ids_b, noise_b, lens2):
+    """TextTransformer.encode of TWO batches of one shape (the auto-encoder and the supervised sub-step of one generator phase, same
+    weights: /root/reference/src/train.py:609-628) with the encoder stack run ONCE over 2B sequences.  What the reference keeps per call
+    stays per half: the conv front end with its BatchNorm batch statistics and running-stat updates (first a, then b), the dropout /
+    noise streams.  Returns the stack's output Var [2 B T, E] (rows of a, then rows of b)."""
+    B, T = ids_a.shape
+    a = m.args
+    E = cx.P["text_m.prenet.embed.weight"].shape[1]
+    buf = _empty(2 * B * T, E, device=ids_a.device)
+    xa = text_frontend(cx, tape, m, ids_a, noise_a, out=buf[:B * T])
+    xb = text_frontend(cx, tape, m, ids_b, noise_b, out=buf[B * T:])
+    x2 = _stack_rows(cx, tape, (xa, xb), buf)
+    return encoder_stack(cx, tape, x2, lens2, "text_m.encoder.transformer_encoder.layers.", a.num_layers, 2 * B, T, a.nhead, a.e_drop)
 
 
 def text_decode(cx, tape, m, ids, lens_q, mem, lens_k, Tk, shift=True):
@@ -386,7 +426,7 @@ def text_decode(cx, tape, m, ids, lens_q, mem, lens_k, Tk, shift=True):
 # ---------------------------------------------------------------------------------------------------------------
 # Speech side
 # ---------------------------------------------------------------------------------------------------------------
-def speech_prenet(cx, tape, m, mel2d, T):
+def speech_prenet(cx, tape, m, mel2d, T, out=None):
     """SpeechPrenet (src/module.py:76-110; ONE dropout) followed by PositionalEncoding."""
     a = m.args
     N = mel2d.shape[0]
@@ -411,21 +451,40 @@ def speech_prenet(cx, tape, m, mel2d, T):
             ops.linear_dgrad(d2, W2, du, G=h1, gate_scale=(1.0 / (1.0 - p) if p > 0 else 1.0))
             ops.linear_wgrad(du, mel2d, st.g("speech_m.prenet.layer.fc1.linear_layer.weight"), db=st.g("speech_m.prenet.layer.fc1.linear_layer.bias"))
         tape.record(bwd)                                # recorded before posenc's closure => runs after it
-    y = posenc(cx, tape, h2v, m.pe, T, gate=h2)
+    y = posenc(cx, tape, h2v, m.pe, T, gate=h2, out=out)
     return y
+
+
+def speech_frontend(cx, tape, m, mel, noise, out=None):
+    """noise_fn on the raw mel, SpeechPrenet and the positional encoding in front of the speech encoder stack (src/network.py:203-206)."""
+    B, T, M = mel.shape
+    mel2d = mel.reshape(B * T, M)
+    if noise and cx.noisy:
+        noised = _empty(B * T, M, like=mel2d)
+        ops.rowmask(mel2d, noised, 0.3, cx.seed, cx.stream())
+        mel2d = noised
+    return speech_prenet(cx, tape, m, mel2d, T, out=out)
 
 
 def speech_encode(cx, tape, m, mel, lens, noise):
     """SpeechTransformer.encode (src/network.py:203-208)."""
     B, T, M = mel.shape
     a = m.args
-    mel2d = mel.reshape(B * T, M)
-    if noise and cx.noisy:
-        noised = _empty(B * T, M, like=mel2d)
-        ops.rowmask(mel2d, noised, 0.3, cx.seed, cx.stream())
-        mel2d = noised
-    x = speech_prenet(cx, tape, m, mel2d, T)
+    x = speech_frontend(cx, tape, m, mel, noise)
     return encoder_stack(cx, tape, x, lens, "speech_m.encoder.transformer_encoder.layers.", a.num_layers, B, T, a.nhead, a.e_drop)
+
+
+def speech_encode_pair(cx, tape, m, mel_a, noise_a, mel_b, noise_b, lens2):
+    """SpeechTransformer.encode of two batches of one shape with the encoder stack run once over 2B sequences (see text_encode_pair; the
+    speech front end has no batch statistics, its dropout / noise streams stay per half)."""
+    B, T, M = mel_a.shape
+    a = m.args
+    E = cx.P["speech_m.prenet.layer.fc2.linear_layer.weight"].shape[0]
+    buf = _empty(2 * B * T, E, like=mel_a)
+    xa = speech_frontend(cx, tape, m, mel_a, noise_a, out=buf[:B * T])
+    xb = speech_frontend(cx, tape, m, mel_b, noise_b, out=buf[B * T:])
+    x2 = _stack_rows(cx, tape, (xa, xb), buf)
+    return encoder_stack(cx, tape, x2, lens2, "speech_m.encoder.transformer_encoder.layers.", a.num_layers, 2 * B, T, a.nhead, a.e_drop)
 
 
 def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk, shift=True, postnet=True):

@@ -91,7 +91,7 @@ class GraphedTrainStep:
         shp = lambda k, n: tuple((k, i, tuple(tuple(t.shape) for t in batches[k][i])) for i in range(n))
         gen = shp("unsup", a.ae_steps) + shp("sup", a.sp_steps)
         disc = shp("disc", a.d_steps) if a.use_discriminator else ()
-        return gen, disc, (is_deterministic(), config.NSPLIT, self.model.training)
+        return gen, disc, (is_deterministic(), config.NSPLIT, self.model.training, config.JOINT_GEN)
 
     @staticmethod
     def _static_like(batch, dev):
@@ -132,11 +132,15 @@ class GraphedTrainStep:
         if a.use_discriminator:
             T.freeze_model_parameters(model.discriminator)
         accum = a.ae_steps + a.sp_steps
-        subs = [(T.train_ae_step, b) for b in self.static["unsup"]] + [(T.train_sp_step, b) for b in self.static["sup"]]
-        for i, (fn, b) in enumerate(subs):
-            if i == len(subs) - 1:
-                ddp.arm()                      # last generator sub-step: gradient buckets travel during its backward (no-op when not distributed)
-            fn(losses, model, b, 0, accum, a)
+        if a.ae_steps == 1 and a.sp_steps == 1 and T.joint_generator_phase(a, self.static["unsup"][0], self.static["sup"][0]):
+            ddp.arm()
+            T.train_gen_joint_step(losses, model, self.static["unsup"][0], self.static["sup"][0], 0, accum, a)
+        else:
+            subs = [(T.train_ae_step, b) for b in self.static["unsup"]] + [(T.train_sp_step, b) for b in self.static["sup"]]
+            for i, (fn, b) in enumerate(subs):
+                if i == len(subs) - 1:
+                    ddp.arm()                      # last generator sub-step: gradient buckets travel during its backward (no-op when not distributed)
+                fn(losses, model, b, 0, accum, a)
         T.optimizer_step(model, self.opt, a)
 
     def _d_phase(self, losses, defer):

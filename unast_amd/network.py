@@ -113,6 +113,26 @@ def _out3d(tape, var2d, B, T):
     return o
 
 
+def _out3d_rows(tape, var2d, halves, B, T):
+    """The row blocks of a [len(halves) * B * T, C] Var as [B, T, C] output Vars (views).  Their gradients arrive separately (each block
+    has its own consumers) and are gathered into one buffer for the stack's backward: one copy per block."""
+    N = B * T
+    outs = [Var(var2d.v[i * N:(i + 1) * N].view(B, T, var2d.v.shape[1])) for i in range(halves)]
+    if tape is not None:
+        def bwd():
+            if all(o.g is None for o in outs):
+                return
+            g = torch.empty_like(var2d.v)
+            for i, o in enumerate(outs):
+                if o.g is None:
+                    g[i * N:(i + 1) * N].zero_()
+                else:
+                    g[i * N:(i + 1) * N].copy_(o.g.reshape(N, -1))
+            acc(var2d, g)
+        tape.record(bwd)
+    return outs
+
+
 def _alias(tape, var):
     """A second output of the same activation (a view) for a second consumer.  Each of the two then has exactly one user in
     torch's autograd graph and THIS call's backward adds the two incoming gradients itself (on its own stream, after autograd
@@ -168,6 +188,25 @@ class TextTransformer(AutoEncoderNet):
             return [o, _alias(tape, o)]
         enc, enc_hid = run_segment(run, ddp_hook("text_enc", cx.st), cx.st.dummy)
         return enc, (None, lens, enc_hid)
+
+    @on_stream("text")
+    def encode_pair(self, in_a, lens_a, noise_a, in_b, lens_b, noise_b):
+        """encode(in_a, lens_a, noise_a) and encode(in_b, lens_b, noise_b) of two batches of ONE shape as a single call: the front ends
+        per batch (BatchNorm statistics and running-stat updates in the order a, b, as two calls would make them), the encoder stack once
+        over both (unast_amd.functional.text_encode_pair).  Returns the two (enc_outputs, masks) pairs of the separate calls."""
+        if in_a.shape != in_b.shape:
+            raise ValueError("encode_pair: the two batches must have one shape")
+        B, T = in_a.shape
+        la, lb = lens_i32(lens_a, in_a.device), lens_i32(lens_b, in_b.device)
+        lens2 = torch.cat([la, lb])
+        cx = self._ctx()
+        ids_a, ids_b = in_a.contiguous(), in_b.contiguous()
+
+        def run(tape, dummy):
+            oa, ob = _out3d_rows(tape, F.text_encode_pair(cx, tape, self, ids_a, noise_a, ids_b, noise_b, lens2), 2, B, T)
+            return [oa, _alias(tape, oa), ob, _alias(tape, ob)]
+        ea, ha, eb, hb = run_segment(run, ddp_hook("text_enc", cx.st), cx.st.dummy)
+        return (ea, (None, la, ha)), (eb, (None, lb, hb))
 
     @on_stream("text")
     def decode_sequence(self, tgt, tgt_lens, enc_outputs, masks, teacher_ratio=1):
@@ -262,6 +301,23 @@ class SpeechTransformer(AutoEncoderNet):
             return [o, _alias(tape, o)]
         enc, enc_hid = run_segment(run, ddp_hook("speech_enc", cx.st), cx.st.dummy)
         return enc, (None, lens, enc_hid)
+
+    @on_stream("speech")
+    def encode_pair(self, in_a, lens_a, noise_a, in_b, lens_b, noise_b):
+        """Two encode calls of one shape as one (see TextTransformer.encode_pair): front ends per batch, the encoder stack once over both."""
+        if in_a.shape != in_b.shape:
+            raise ValueError("encode_pair: the two batches must have one shape")
+        B, T, M = in_a.shape
+        la, lb = lens_i32(lens_a, in_a.device), lens_i32(lens_b, in_b.device)
+        lens2 = torch.cat([la, lb])
+        cx = self._ctx()
+        mel_a, mel_b = in_a.detach().contiguous(), in_b.detach().contiguous()
+
+        def run(tape, dummy):
+            oa, ob = _out3d_rows(tape, F.speech_encode_pair(cx, tape, self, mel_a, noise_a, mel_b, noise_b, lens2), 2, B, T)
+            return [oa, _alias(tape, oa), ob, _alias(tape, ob)]
+        ea, ha, eb, hb = run_segment(run, ddp_hook("speech_enc", cx.st), cx.st.dummy)
+        return (ea, (None, la, ha)), (eb, (None, lb, hb))
 
     @on_stream("speech")
     def decode_sequence(self, tgt, tgt_lens, enc_outputs, masks, teacher_ratio=1):

@@ -105,11 +105,13 @@ class _LossSum(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         one = _ONES.get(g.device)
-        if one is not None and g.data_ptr() == one.data_ptr():      # seeded by _sum_and_backward: d loss / d part = 1 / div, a resident constant
-            key = (g.device, ctx.div)
+        known = 1.0 if (one is not None and g.data_ptr() == one.data_ptr()) else _KNOWN.get(g.data_ptr())
+        if known is not None:      # seeded by _sum_and_backward (or by an enclosing _LossSum): d loss / d part = g / div, a resident constant
+            key = (g.device, ctx.div / known)
             gg = _INV.get(key)
             if gg is None:
-                gg = _INV[key] = torch.full((), 1.0, dtype=torch.float32, device=g.device) / ctx.div
+                gg = _INV[key] = torch.full((), known, dtype=torch.float32, device=g.device) / ctx.div
+                _KNOWN[gg.data_ptr()] = known / ctx.div
             return (None,) + (gg,) * ctx.n
         gg = torch.empty((), dtype=torch.float32, device=g.device)
         ops.scalar_combine([g.contiguous()], ctx.div, gg)
@@ -118,6 +120,7 @@ class _LossSum(torch.autograd.Function):
 
 _ONES = {}
 _INV = {}
+_KNOWN = {}          # data pointer of a resident constant scalar made here -> its value
 _WS_RING = {}
 
 
@@ -147,11 +150,15 @@ def _loss_ws(dev):
 
 def _sum_and_backward(parts, accum_steps):
     """loss = sum(parts) / accum_steps; loss.backward() seeded from a resident 1.0 (no fill launch).  Device scalars in, device scalar out."""
-    if not all(p.dim() == 0 and p.dtype == torch.float32 and p.is_cuda for p in parts) or len(parts) > 3:
+    if not all(p.dim() == 0 and p.dtype == torch.float32 and p.is_cuda for p in parts) or len(parts) > 9:
         loss = sum(parts[1:], parts[0]) / accum_steps
         loss.backward()
         return loss
-    loss = _LossSum.apply(float(accum_steps), *parts)
+    if len(parts) > 3:              # (the joint generator step has six parts: groups of three, then the sum of the groups)
+        groups = [_LossSum.apply(float(accum_steps), *parts[i:i + 3]) for i in range(0, len(parts), 3)]
+        loss = _LossSum.apply(1.0, *groups)
+    else:
+        loss = _LossSum.apply(float(accum_steps), *parts)
     dev = loss.device
     one = _ONES.get(dev)
     if one is None:
@@ -338,8 +345,9 @@ def crossmodel_step(model, batch, args, use_dis_loss=False):
 
 
 @on_stream("disc")
-def discriminator_shuffle_batch(t_hid, t_hid_len, s_hid, s_hid_len, model_type, train_discriminator=False):
-    """src/train.py:296-329 for model_type == 'transformer'."""
+def discriminator_shuffle_batch(t_hid, t_hid_len, s_hid, s_hid_len, model_type, train_discriminator=False, out=None):
+    """src/train.py:296-329 for model_type == 'transformer'.  out (not in the reference's signature): a [2B, Tmax, D] row block of a larger
+    buffer that receives the batch (train_gen_joint_step puts two sub-steps' batches side by side)."""
     if model_type != 'transformer':
         raise NotImplementedError("only the transformer family is on the MI355X path")
     B, Tt, Dm = t_hid.shape
@@ -354,9 +362,9 @@ def discriminator_shuffle_batch(t_hid, t_hid_len, s_hid, s_hid_len, model_type, 
 
     def run(tape, dummy, th, sh):
         thc, shc = th.v.contiguous(), sh.v.contiguous()
-        out = torch.empty(2 * B, Tmax, Dm, dtype=torch.float32, device=dev)
-        ops.disc_gather(thc, shc, tl, sl, perm, out, d_len)
-        o = Var(out)
+        dst = out if out is not None else torch.empty(2 * B, Tmax, Dm, dtype=torch.float32, device=dev)
+        ops.disc_gather(thc, shc, tl, sl, perm, dst, d_len)
+        o = Var(dst)
         if tape is not None:
             def bwd():
                 if o.g is None:
@@ -459,6 +467,90 @@ def train_ae_step(losses, model, batch, step, accum_steps, args):
     return loss
 
 
+class _JoinRows(torch.autograd.Function):
+    """`buf` already holds the row blocks `parts` (each a view of it, written in place by its producer): returns buf as ONE tensor that
+    autograd connects to every block's producer; the gradient goes back as row-block views.  (torch.cat would copy 2 x 52 MB per call.)"""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.rows = [p.shape[0] for p in parts]
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, r = [], 0
+        for n in ctx.rows:
+            outs.append(g[r:r + n])
+            r += n
+        return (None,) + tuple(outs)
+
+
+def train_gen_joint_step(losses, model, ae_batch, sp_batch, step, accum_steps, args):
+    """train_ae_step(ae_batch) followed by train_sp_step(sp_batch) (src/train.py:392-416, 365-390, called back to back before the one
+    optimizer_step of the generator phase, src/train.py:609-628) as ONE forward and ONE backward.  Gradients of the two sub-steps add up
+    before the update in the reference too, so the joint backward of (ae losses + sp losses) / accum_steps changes no result; what it
+    buys: each encoder runs its stack once over both sub-steps' batches (encode_pair: 2B sequences per launch -- the text side's
+    45-180-workgroup GEMMs double --, BatchNorm statistics / running-stat updates stay per sub-step and in the reference's order), the
+    frozen LSTM discriminator scores both sub-steps' encoder outputs in one call (4B sequences: 256 workgroups per recurrent launch
+    instead of 128, 8 launches per step instead of 12), and the two sub-steps' decoders are independent work on two streams.
+    Needs both batches in one shape; otherwise (or with config.JOINT_GEN off) the caller runs the two sub-steps one after the other."""
+    (xa, ya), (xs, ys) = process_batch(ae_batch), process_batch(sp_batch)
+    text_a, mel_a, tl_a, ml_a = xa
+    text_s, mel_s, tl_s, ml_s = xs
+    use_d = bool(args.use_discriminator)
+    with side_streams():
+        mel_aug = mel_s if is_deterministic() else specaugment(mel_s, ml_s)
+        (t_enc_a, t_masks_a), (t_enc_s, t_masks_s) = model.text_m.encode_pair(text_a, tl_a, True, text_s, tl_s, False)
+        (s_enc_a, s_masks_a), (s_enc_s, s_masks_s) = model.speech_m.encode_pair(mel_a, ml_a, True, mel_aug, ml_s, False)
+        if use_d:       # both sub-steps' discriminator batches side by side in one buffer, one discriminator call
+            B, Tmax, Dm = text_a.shape[0], max(text_a.shape[1], mel_a.shape[1]), t_enc_a.shape[-1]
+            with torch.cuda.stream(stream_of("disc") or torch.cuda.current_stream()):
+                d_buf = torch.empty(4 * B, Tmax, Dm, dtype=torch.float32, device=t_enc_a.device)
+            d_a = discriminator_shuffle_batch(t_masks_a[2], tl_a, s_masks_a[2], ml_a, args.model_type, out=d_buf[:2 * B])
+            d_s = discriminator_shuffle_batch(t_masks_s[2], tl_s, s_masks_s[2], ml_s, args.model_type, out=d_buf[2 * B:])
+            d_ae_loss, d_sp_loss = _discriminator_pair_losses(model, d_buf, d_a, d_s)
+        # the auto-encoder sub-step's decoders, then the supervised sub-step's (BatchNorm of the speech post-net: first ae, then tts)
+        text_pred_a = model.text_m.decode_sequence(text_a, tl_a, t_enc_a, t_masks_a).permute(0, 2, 1)
+        pre_a, post_a, stop_a, _ = model.speech_m.decode_sequence(mel_a, ml_a, s_enc_a, s_masks_a)
+        pre_s, post_s, stop_s, _ = model.speech_m.decode_sequence(mel_s, ml_s, t_enc_s, t_masks_s)
+        text_pred_s = model.text_m.decode_sequence(text_s, tl_s, s_enc_s, s_masks_s).permute(0, 2, 1)
+        s_ae_loss = speech_loss(ya[1], ya[2], pre_a, post_a, ml_a, stop_a, args.s_eos_weight)
+        t_ae_loss = text_loss(ya[0], text_pred_a, args.t_eos_weight)
+        tts_loss = speech_loss(ys[1], ys[2], pre_s, post_s, ml_s, stop_s, args.s_eos_weight)
+        asr_loss = text_loss(ys[0], text_pred_s, args.t_eos_weight)
+        join_streams()
+        parts = [t_ae_loss, s_ae_loss] + ([d_ae_loss] if use_d else []) + [tts_loss, asr_loss] + ([d_sp_loss] if use_d else [])
+        loss = _sum_and_backward(parts, accum_steps)
+    losses['t_ae'].append(_log(t_ae_loss))
+    losses['s_ae'].append(_log(s_ae_loss))
+    if use_d:
+        losses['d_ae'].append(_log(d_ae_loss))
+    losses['asr_'].append(_log(asr_loss))
+    losses['tts_'].append(_log(tts_loss))
+    if use_d:
+        losses['sp_d'].append(_log(d_sp_loss))
+    return loss
+
+
+@on_stream("disc")
+def _discriminator_pair_losses(model, d_buf, d_a, d_s):
+    """discriminator_hidden_to_loss of two discriminator batches whose hidden states sit side by side in `d_buf`: one discriminator
+    call over both (the two batches' rows keep their own dropout decisions: masks are drawn per row), one loss per batch."""
+    n = d_a[0].shape[0]
+    d_hid = _JoinRows.apply(d_buf, d_a[0], d_s[0])
+    d_out = model.discriminator(d_hid, torch.cat([d_a[1], d_s[1]]))
+    return discriminator_loss(d_out[:n], d_a[2]), discriminator_loss(d_out[n:], d_s[2])
+
+
+def joint_generator_phase(args, ae_batch, sp_batch):
+    """Whether the generator phase of one outer step can run as train_gen_joint_step: one auto-encoder and one supervised sub-step, no
+    cross-model sub-step between them, and the two batches in one shape."""
+    from . import config
+    if not config.JOINT_GEN or args.ae_steps != 1 or args.sp_steps != 1 or getattr(args, "cm_steps", 0) != 0:
+        return False
+    return all(tuple(a.shape) == tuple(b.shape) for a, b in zip(ae_batch[:2], sp_batch[:2]))
+
+
 def train_cm_step(losses, model, batch, step, accum_steps, args):
     """src/train.py:418-444."""
     batch = process_batch(batch)
@@ -521,13 +613,17 @@ def train_step(losses, model, optimizer, scheduler, batches, step, args, defer_d
     if args.use_discriminator:
         freeze_model_parameters(model.discriminator)
     accum_steps = args.ae_steps + getattr(args, "cm_steps", 0) + args.sp_steps
-    subs = [(train_ae_step, batches["unsup"][si]) for si in range(args.ae_steps)]
-    subs += [(train_cm_step, batches["cm"][si]) for si in range(getattr(args, "cm_steps", 0))]
-    subs += [(train_sp_step, batches["sup"][si]) for si in range(args.sp_steps)]
-    for i, (fn, b) in enumerate(subs):
-        if i == len(subs) - 1:
-            ddp.arm()          # gradients become final in this sub-step: buckets travel as soon as their backward is enqueued
-        fn(losses, model, b, step, accum_steps, args)
+    if args.ae_steps == 1 and args.sp_steps == 1 and joint_generator_phase(args, batches["unsup"][0], batches["sup"][0]):
+        ddp.arm()              # one backward for the whole generator phase: every bucket is final when its users have run theirs
+        train_gen_joint_step(losses, model, batches["unsup"][0], batches["sup"][0], step, accum_steps, args)
+    else:
+        subs = [(train_ae_step, batches["unsup"][si]) for si in range(args.ae_steps)]
+        subs += [(train_cm_step, batches["cm"][si]) for si in range(getattr(args, "cm_steps", 0))]
+        subs += [(train_sp_step, batches["sup"][si]) for si in range(args.sp_steps)]
+        for i, (fn, b) in enumerate(subs):
+            if i == len(subs) - 1:
+                ddp.arm()          # gradients become final in this sub-step: buckets travel as soon as their backward is enqueued
+            fn(losses, model, b, step, accum_steps, args)
     optimizer_step(model, optimizer, args)
     if args.use_discriminator:
         unfreeze_model_parameters(model.discriminator)
