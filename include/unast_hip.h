@@ -145,6 +145,10 @@ int unast_rowmask(const float* x, float* y, int rows, int D, float p, unsigned i
                   hipStream_t stream);
 /* a += b : gradient accumulation for activations consumed by several ops (autograd's implicit add). */
 int unast_add_inplace(float* a, const float* b, int64_t n, hipStream_t stream);
+/* dst = a + b over n floats (b may be NULL: a copy).  The gradients that reach the two halves of a paired encoder call (its decoder's
+ * and the discriminator's, autograd of TextTransformer / SpeechTransformer.encode, src/network.py:203-208, 427-444) are summed straight
+ * into their row block of the stack's gradient buffer; a kernel, not a memcpy, so that it can live in a captured step. */
+int unast_sum2(float* dst, const float* a, const float* b, int64_t n, hipStream_t stream);
 /* Autoregressive inference helpers (TextTransformer/SpeechTransformer.infer_sequence, src/network.py:219-252, 455-481):
  * first-maximum argmax per row of the logits, and zeroing of generated frames/tokens at t >= lens[b] (int64 lengths). */
 int unast_argmax_rows(const float* x, int ld, int rows, int cols, int64_t* out, hipStream_t stream);

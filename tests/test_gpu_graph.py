@@ -53,7 +53,7 @@ def _run_steps(graphed, use_disc, lr, n=6):
         from unast_amd import graphed as G
         rec = next(iter(stepper.graphs.values()))
         if G.REPLAY == "streams":          # the executor understood every node of the captured step (no silent fallback)
-            assert rec.plan and rec.plan_info["kernels"] > 300 and rec.plan_info["cross_stream_edges"] > 10, rec.plan_info
+            assert rec.plan and rec.plan_info["kernels"] > 300 and rec.plan_info["cross_stream_edges"] > 5, rec.plan_info
         else:
             assert not rec.plan
         stepper.flush(losses)

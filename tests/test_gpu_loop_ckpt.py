@@ -115,6 +115,9 @@ def test_checkpoint_roundtrip_and_torch_adamw_format(tmp_path):
     ep, vl, model2, opt2 = load_ckp(str(tmp_path / "model_best.ckpt"), model2, opt2)
     assert ep == 1 and vl == 1.0
     train.train_step(defaultdict(list), model2, opt2, None, batches, 1, args)
-    diff = (model2._store().flat - after_orig).abs().max().item()
-    assert diff < 5e-5, diff        # bias-gradient atomics are order-nondeterministic (1e-7 relative); Adam normalises them up to ~3e-6
+    st2 = model2._store()
+    dd = (st2.flat - after_orig).abs()
+    diff = dd.max().item()
+    worst = max((n for n, o in st2.offsets.items() if o <= int(dd.argmax())), key=lambda n: st2.offsets[n])
+    assert diff < 5e-5, (diff, worst, int((dd > 5e-5).sum()))        # bias-gradient atomics are order-nondeterministic (1e-7 relative); Adam normalises them up to ~3e-6
     utils.set_deterministic(False)

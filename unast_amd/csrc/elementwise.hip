@@ -149,6 +149,17 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a,
         for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) a[i] += b[i];
 }
 
+// dst = a + b (b may be null: dst = a): two gradient contributions of one tensor gathered into a row block of a larger buffer in one pass
+__global__ __launch_bounds__(256) void sum2_kernel(float* __restrict__ dst, const float* __restrict__ a, const float* __restrict__ b, size_t n4, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 x = reinterpret_cast<const float4*>(a)[i];
+        if (b) { const float4 y = reinterpret_cast<const float4*>(b)[i]; x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w; }
+        reinterpret_cast<float4*>(dst)[i] = x;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) dst[i] = a[i] + (b ? b[i] : 0.f);
+}
+
 // a *= alpha (gradient averaging after the data-parallel all-reduce)
 __global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ a, float alpha, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] *= alpha;
@@ -347,6 +358,13 @@ extern "C" int unast_add_inplace(float* a, const float* b, int64_t n, hipStream_
     UNAST_REQUIRE((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "unast_add_inplace: operands must be 16-byte aligned");
     hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_grid((size_t)n / 4 + 1)), dim3(256), 0, stream, a, b, (size_t)n / 4, (size_t)n);
     return unast_check_launch("unast_add_inplace");
+}
+
+extern "C" int unast_sum2(float* dst, const float* a, const float* b, int64_t n, hipStream_t stream) {
+    UNAST_REQUIRE(dst && a && n > 0, "unast_sum2: bad arguments");
+    UNAST_REQUIRE((((uintptr_t)dst | (uintptr_t)a | (uintptr_t)b) & 15) == 0, "unast_sum2: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(sum2_kernel, dim3(ew_grid((size_t)n / 4 + 1)), dim3(256), 0, stream, dst, a, b, (size_t)n / 4, (size_t)n);
+    return unast_check_launch("unast_sum2");
 }
 
 extern "C" int unast_scale_inplace(float* a, float alpha, int64_t n, hipStream_t stream) {

@@ -14,6 +14,7 @@
 // makes plan creation fail with an error string; the caller then falls back to hipGraphLaunch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include <algorithm>
 #include <map>
 #include <string>
@@ -33,6 +34,7 @@ struct PlanOp {
     hipKernelNodeParams kp;     // OP_KERNEL
     hipMemsetParams ms;         // OP_MEMSET
     void* cdst; const void* csrc; size_t cbytes; hipMemcpyKind ckind;   // OP_MEMCPY
+    size_t crows, cdpitch, cspitch;                                     // rows > 1: a pitched (2-D) copy of `crows` rows of `cbytes` bytes
     float* rbuf; long long rcount;                                      // OP_ALLREDUCE (a captured unast_allreduce_marker)
 };
 
@@ -119,11 +121,21 @@ extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
             ++plan->memsets;
         } else if (type == hipGraphNodeTypeMemcpy) {
             hipMemcpy3DParms cp;
-            if (hipGraphMemcpyNodeGetParams(nodes[v], &cp) != hipSuccess || cp.extent.height > 1 || cp.extent.depth > 1 || cp.srcArray || cp.dstArray ||
+            memset(&cp, 0, sizeof(cp));
+            const hipError_t ge = hipGraphMemcpyNodeGetParams(nodes[v], &cp);
+            if (ge != hipSuccess || cp.extent.depth > 1 || cp.srcArray || cp.dstArray ||
                 cp.srcPos.x || cp.srcPos.y || cp.srcPos.z || cp.dstPos.x || cp.dstPos.y || cp.dstPos.z) {
-                unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: unsupported memcpy node %d (only 1-D copies)", v); return 0;
+                unast_graph_plan_destroy((int64_t)(intptr_t)plan);
+                unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: unsupported memcpy node %d (only linear and pitched 2-D copies; get-params rc %d, extent %zu x %zu x %zu, "
+                                "src pos %zu %zu %zu, dst pos %zu %zu %zu, arrays %d %d, kind %d)", v, (int)ge, cp.extent.width, cp.extent.height, cp.extent.depth,
+                                cp.srcPos.x, cp.srcPos.y, cp.srcPos.z, cp.dstPos.x, cp.dstPos.y, cp.dstPos.z, cp.srcArray != nullptr, cp.dstArray != nullptr, (int)cp.kind);
+                return 0;
             }
             op.kind = OP_MEMCPY; op.cdst = cp.dstPtr.ptr; op.csrc = cp.srcPtr.ptr; op.cbytes = cp.extent.width; op.ckind = cp.kind;
+            op.crows = cp.extent.height > 1 ? cp.extent.height : 1; op.cdpitch = cp.dstPtr.pitch; op.cspitch = cp.srcPtr.pitch;
+            if (op.crows > 1 && (op.cdpitch < op.cbytes || op.cspitch < op.cbytes)) {
+                unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: memcpy node %d: pitch below the row width", v); return 0;
+            }
             if (!op.cdst || !op.csrc || op.cbytes == 0) {            // (a getter that returns zeroed parameters must not become a silent 0-byte copy)
                 unast_graph_plan_destroy((int64_t)(intptr_t)plan); unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: memcpy node %d without a pointer / extent", v); return 0;
             }
@@ -198,7 +210,10 @@ extern "C" int unast_graph_plan_replay(int64_t handle, hipStream_t origin) {
                 else if (op.ms.elementSize == 2) e = hipMemsetD16Async((hipDeviceptr_t)op.ms.dst, (unsigned short)op.ms.value, op.ms.width, s);
                 else e = hipMemsetD32Async((hipDeviceptr_t)op.ms.dst, (int)op.ms.value, op.ms.width, s);
                 break;
-            case OP_MEMCPY: e = hipMemcpyAsync(op.cdst, op.csrc, op.cbytes, op.ckind, s); break;
+            case OP_MEMCPY:
+                e = op.crows > 1 ? hipMemcpy2DAsync(op.cdst, op.cdpitch, op.csrc, op.cspitch, op.cbytes, op.crows, op.ckind, s)
+                                 : hipMemcpyAsync(op.cdst, op.csrc, op.cbytes, op.ckind, s);
+                break;
             case OP_RECORD: e = hipEventRecord(plan->events[op.event], s); break;
             case OP_WAIT: e = hipStreamWaitEvent(s, plan->events[op.event], 0); break;
             case OP_ALLREDUCE: {

@@ -586,6 +586,12 @@ class FlatStore:
             self.refresh_T()
             self.refresh_planes()
             self._split_ver = ver
+            # The copies were remade on whatever stream the first public call after the write runs on (inside train_*_step: a side stream),
+            # and the next call -- on ANOTHER side stream -- reads them a few microseconds later: the joint generator step, which issues
+            # the text and the speech encoder back to back, read stale copies in one of three runs right after load_ckp
+            # (tests/test_gpu_loop_ckpt.py).  Rare path (a torch-side write), so: the host waits here and every later launch is behind it.
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().synchronize()
 
     # combined operands ---------------------------------------------------------------------------------------
     def span(self, first, last, shape, grad=False):

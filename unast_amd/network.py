@@ -113,21 +113,28 @@ def _out3d(tape, var2d, B, T):
     return o
 
 
-def _out3d_rows(tape, var2d, halves, B, T):
-    """The row blocks of a [len(halves) * B * T, C] Var as [B, T, C] output Vars (views).  Their gradients arrive separately (each block
-    has its own consumers) and are gathered into one buffer for the stack's backward: one copy per block."""
-    N = B * T
-    outs = [Var(var2d.v[i * N:(i + 1) * N].view(B, T, var2d.v.shape[1])) for i in range(halves)]
+def _pair_outputs(tape, var2d, B, T):
+    """The two row blocks of a [2 B T, C] Var (a paired encoder call's stack output) as [B, T, C] output Vars, each twice: the value and
+    a second alias of it for its second consumer (see _alias: the decoder and the discriminator both read an encoder output, on two
+    streams).  The four gradients arrive separately; the stack's backward wants one buffer: each block = value gradient + alias gradient,
+    summed straight into its rows by one kernel per block (no memcpy node in a captured step, no separate accumulate pass)."""
+    N, C = B * T, var2d.v.shape[1]
+    outs = []
+    for i in range(2):
+        blk = var2d.v[i * N:(i + 1) * N].view(B, T, C)
+        outs += [Var(blk), Var(blk.view(B, T, C))]
     if tape is not None:
         def bwd():
             if all(o.g is None for o in outs):
                 return
             g = torch.empty_like(var2d.v)
-            for i, o in enumerate(outs):
-                if o.g is None:
-                    g[i * N:(i + 1) * N].zero_()
+            for i in range(2):
+                parts = [o.g if o.g.is_contiguous() else o.g.contiguous() for o in outs[2 * i:2 * i + 2] if o.g is not None]
+                dst = g[i * N:(i + 1) * N]
+                if not parts:
+                    dst.zero_()
                 else:
-                    g[i * N:(i + 1) * N].copy_(o.g.reshape(N, -1))
+                    ops.sum2(dst, parts[0], parts[1] if len(parts) > 1 else None)
             acc(var2d, g)
         tape.record(bwd)
     return outs
@@ -203,8 +210,7 @@ class TextTransformer(AutoEncoderNet):
         ids_a, ids_b = in_a.contiguous(), in_b.contiguous()
 
         def run(tape, dummy):
-            oa, ob = _out3d_rows(tape, F.text_encode_pair(cx, tape, self, ids_a, noise_a, ids_b, noise_b, lens2), 2, B, T)
-            return [oa, _alias(tape, oa), ob, _alias(tape, ob)]
+            return _pair_outputs(tape, F.text_encode_pair(cx, tape, self, ids_a, noise_a, ids_b, noise_b, lens2), B, T)
         ea, ha, eb, hb = run_segment(run, ddp_hook("text_enc", cx.st), cx.st.dummy)
         return (ea, (None, la, ha)), (eb, (None, lb, hb))
 
@@ -314,8 +320,7 @@ class SpeechTransformer(AutoEncoderNet):
         mel_a, mel_b = in_a.detach().contiguous(), in_b.detach().contiguous()
 
         def run(tape, dummy):
-            oa, ob = _out3d_rows(tape, F.speech_encode_pair(cx, tape, self, mel_a, noise_a, mel_b, noise_b, lens2), 2, B, T)
-            return [oa, _alias(tape, oa), ob, _alias(tape, ob)]
+            return _pair_outputs(tape, F.speech_encode_pair(cx, tape, self, mel_a, noise_a, mel_b, noise_b, lens2), B, T)
         ea, ha, eb, hb = run_segment(run, ddp_hook("speech_enc", cx.st), cx.st.dummy)
         return (ea, (None, la, ha)), (eb, (None, lb, hb))
 

@@ -511,6 +511,11 @@ def add_inplace(a, b):
     check(lib().unast_add_inplace(_p(a), _p(b), a.numel(), _stream()), "unast_add_inplace")
 
 
+def sum2(dst, a, b=None):
+    """dst = a + b (b None: dst = a), contiguous fp32 tensors of one size."""
+    check(lib().unast_sum2(_p(dst), _p(a), _p(b), dst.numel(), _stream()), "unast_sum2")
+
+
 def argmax_rows(x2d, cols, out_i64):
     check(lib().unast_argmax_rows(_p(x2d), x2d.stride(0), x2d.shape[0], cols, _p(out_i64), _stream()), "unast_argmax_rows")
 

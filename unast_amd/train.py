@@ -467,6 +467,10 @@ def train_ae_step(losses, model, batch, step, accum_steps, args):
     return loss
 
 
+_JOINT_D_FIRST = os.environ.get("UNAST_JOINT_D_FIRST", "0") == "1"       # experiment switches of train_gen_joint_step
+_JOINT_D_PAIR = os.environ.get("UNAST_JOINT_D_PAIR", "1") != "0"
+
+
 class _JoinRows(torch.autograd.Function):
     """`buf` already holds the row blocks `parts` (each a view of it, written in place by its producer): returns buf as ONE tensor that
     autograd connects to every block's producer; the gradient goes back as row-block views.  (torch.cat would copy 2 x 52 MB per call.)"""
@@ -502,18 +506,30 @@ def train_gen_joint_step(losses, model, ae_batch, sp_batch, step, accum_steps, a
         mel_aug = mel_s if is_deterministic() else specaugment(mel_s, ml_s)
         (t_enc_a, t_masks_a), (t_enc_s, t_masks_s) = model.text_m.encode_pair(text_a, tl_a, True, text_s, tl_s, False)
         (s_enc_a, s_masks_a), (s_enc_s, s_masks_s) = model.speech_m.encode_pair(mel_a, ml_a, True, mel_aug, ml_s, False)
-        if use_d:       # both sub-steps' discriminator batches side by side in one buffer, one discriminator call
-            B, Tmax, Dm = text_a.shape[0], max(text_a.shape[1], mel_a.shape[1]), t_enc_a.shape[-1]
-            with torch.cuda.stream(stream_of("disc") or torch.cuda.current_stream()):
-                d_buf = torch.empty(4 * B, Tmax, Dm, dtype=torch.float32, device=t_enc_a.device)
-            d_a = discriminator_shuffle_batch(t_masks_a[2], tl_a, s_masks_a[2], ml_a, args.model_type, out=d_buf[:2 * B])
-            d_s = discriminator_shuffle_batch(t_masks_s[2], tl_s, s_masks_s[2], ml_s, args.model_type, out=d_buf[2 * B:])
-            d_ae_loss, d_sp_loss = _discriminator_pair_losses(model, d_buf, d_a, d_s)
+        def disc_losses():
+            if not use_d:
+                return None, None
+            if _JOINT_D_PAIR:       # both sub-steps' discriminator batches side by side in one buffer, one discriminator call
+                B, Tmax, Dm = text_a.shape[0], max(text_a.shape[1], mel_a.shape[1]), t_enc_a.shape[-1]
+                with torch.cuda.stream(stream_of("disc") or torch.cuda.current_stream()):
+                    d_buf = torch.empty(4 * B, Tmax, Dm, dtype=torch.float32, device=t_enc_a.device)
+                d_a = discriminator_shuffle_batch(t_masks_a[2], tl_a, s_masks_a[2], ml_a, args.model_type, out=d_buf[:2 * B])
+                d_s = discriminator_shuffle_batch(t_masks_s[2], tl_s, s_masks_s[2], ml_s, args.model_type, out=d_buf[2 * B:])
+                return _discriminator_pair_losses(model, d_buf, d_a, d_s)
+            d_a = discriminator_shuffle_batch(t_masks_a[2], tl_a, s_masks_a[2], ml_a, args.model_type)
+            la_, _ = discriminator_hidden_to_loss(model, d_a, freeze_discriminator=True)
+            d_s = discriminator_shuffle_batch(t_masks_s[2], tl_s, s_masks_s[2], ml_s, args.model_type)
+            ls_, _ = discriminator_hidden_to_loss(model, d_s, freeze_discriminator=True)
+            return la_, ls_
+        if _JOINT_D_FIRST:
+            d_ae_loss, d_sp_loss = disc_losses()
         # the auto-encoder sub-step's decoders, then the supervised sub-step's (BatchNorm of the speech post-net: first ae, then tts)
         text_pred_a = model.text_m.decode_sequence(text_a, tl_a, t_enc_a, t_masks_a).permute(0, 2, 1)
         pre_a, post_a, stop_a, _ = model.speech_m.decode_sequence(mel_a, ml_a, s_enc_a, s_masks_a)
         pre_s, post_s, stop_s, _ = model.speech_m.decode_sequence(mel_s, ml_s, t_enc_s, t_masks_s)
         text_pred_s = model.text_m.decode_sequence(text_s, tl_s, s_enc_s, s_masks_s).permute(0, 2, 1)
+        if not _JOINT_D_FIRST:
+            d_ae_loss, d_sp_loss = disc_losses()
         s_ae_loss = speech_loss(ya[1], ya[2], pre_a, post_a, ml_a, stop_a, args.s_eos_weight)
         t_ae_loss = text_loss(ya[0], text_pred_a, args.t_eos_weight)
         tts_loss = speech_loss(ys[1], ys[2], pre_s, post_s, ml_s, stop_s, args.s_eos_weight)
