@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-3 measurement passes on the MI355X box (repo root).  usage: bash tools/run_r03_measure.sh <pass> [tag]
+# Round-4 measurement passes on the MI355X box (repo root).  usage: bash tools/run_r04_measure.sh <pass> [tag]
 #   pass A: tests, the default bench line, configs 2 and 5, kernel statistics of the bench command (four streams / single stream)
 #   pass B: HBM traffic and attention PMC passes, chip-idle trace of the replayed step, torch-native launch attribution, panel stamps and
 #           micro-benchmarks.  Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
-pass=${1:-A}; tag=${2:-r3_final}; R=$PWD; O=$R/gpurun_out/$tag
+pass=${1:-A}; tag=${2:-r4_final}; R=$PWD; O=$R/gpurun_out/$tag
 mkdir -p $O
 set -x
 if [ "$pass" = "A" ]; then

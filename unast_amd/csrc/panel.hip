@@ -324,6 +324,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void panel_kernel(const PanelParam
     auto run_epilogue = [&](int cg, f32x4 (&ac)[RT][2]) {
         STAMP(te0);
         using T = std::true_type; using F = std::false_type;
+#ifdef PKO_PLAIN_EPILOGUE
+        if (64 * cg + 64 <= p.N) { epilogue_fast(cg, ac, F{}, F{}, F{}, F{}, F{}); st_now += s_fast; return; }
+#endif
+#ifdef PKO_NO_EPILOGUE
+        if (64 * cg + 64 <= p.N) { asm volatile("" :: "v"(ac[0][0]), "v"(ac[0][1])); return; }
+#endif
         if (epi_kind == 0 || 64 * cg + 64 > p.N) {
             epilogue(cg, ac);
         } else {
@@ -373,17 +379,24 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void panel_kernel(const PanelParam
             };
             STAMP(tm0);
             load_b(K0 & 1, K0);
+#ifdef PKO_NO_LDS_READS
+            load_b((K0 + 1) & 1, K0);
+#endif
 #pragma unroll
             for (int ks = K0; ks < K1; ++ks) {
+#ifndef PKO_NO_LDS_READS
                 if (ks + 1 < K1) load_b((ks + 1) & 1, ks + 1);
+#endif
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
                     const bf16x8_t bh = bf[ks & 1][c2][0], bl = bf[ks & 1][c2][1];
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
                         // weights as the MFMA "A" (rows = n): each lane ends up with 4 consecutive n of row m = l15
+#ifndef PKO_ONE_MFMA        // (PKO_*: timing-only knock-out builds, tools/panel_knockout.sh; never defined in the shipped library)
                         ac[rt][c2] = mfma16(bl, ah[rt][ks], ac[rt][c2]);
                         ac[rt][c2] = mfma16(bh, al[rt][ks], ac[rt][c2]);
+#endif
                         ac[rt][c2] = mfma16(bh, ah[rt][ks], ac[rt][c2]);
                     }
                 }
