@@ -224,6 +224,13 @@ int unast_text_loss_fwd(const float* logits, int ldl, const int64_t* gold, int r
                         double* ws, float* loss, hipStream_t stream);
 int unast_text_loss_bwd(const float* logits, int ldl, const int64_t* gold, int rows, int V, float eos_weight, const double* ws,
                         const float* gscale, float* dlogits, hipStream_t stream);
+/* The text head AND its loss in one launch (north_star: "heads plus losses fused"): logits[rows, ldl] = X[rows, K = 256] W[V, K]^T + bias
+ * (TextPostnet.fc1, src/module.py:243-246), text_loss of them (src/train.py:105-111: weighted cross-entropy, ignore_index 0, EOS = 2 weighted)
+ * and dlogits = gscale * d(loss)/d(logits) -- the softmax runs on the head GEMM's accumulators (a workgroup holds whole rows: V <= 48),
+ * the logits are stored once for the caller, the normaliser sum(w) is recomputed from `gold` by every workgroup.  gscale: the upstream
+ * gradient of the loss as the HOST knows it (1 / accum_steps in the train step); ws: as unast_text_loss_fwd. */
+int unast_text_head_loss(const float* X, int ldx, const float* W, const float* bias, const int64_t* gold, int rows, int K, int V,
+                         float eos_weight, float gscale, float* logits, float* dlogits, int ldl, double* ws, float* loss, hipStream_t stream);
 /* discriminator_target (src/train.py:150-164, 319-320): smoothed labels 0.9 (text rows: perm[i] < B) / 0.1 (speech),
  * flipped (1-y) when flip=1 (generator phase). */
 int unast_disc_targets(const int64_t* perm, int n, int B, int flip, float smoothing, float* out, hipStream_t stream);

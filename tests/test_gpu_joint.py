@@ -34,8 +34,10 @@ def test_joint_generator_step_equals_the_two_substeps(shape, use_disc):
     from unast_amd.portable import synth_batch
     ae = tuple(torch.from_numpy(x) for x in synth_batch(*shape, seed=1, ragged=True))
     sp = tuple(torch.from_numpy(x) for x in synth_batch(*shape, seed=2, ragged=True))           # another batch of the same shape
+    from unast_amd import functional as F
     res = []
     for joint in (False, True):
+        before = dict(F.FUSED_STATS)
         args, model, opt = build(2, 1e-3, use_disc)
         losses = defaultdict(list)
         model.train()
@@ -49,6 +51,11 @@ def test_joint_generator_step_equals_the_two_substeps(shape, use_disc):
             train.train_sp_step(losses, model, sp, 0, 2, args)
         model.expose_grads()
         torch.cuda.synchronize()
+        used = {k: F.FUSED_STATS[k] - before[k] for k in before}
+        if joint:       # the heads computed their losses and gradients themselves, and the loss calls took those gradients as they were
+            assert used["text_head"] == 2 and used["text_grad_direct"] == 2 and used["text_grad_general"] == 0, used
+        else:
+            assert all(v == 0 for v in used.values()), used
         grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
         bufs = {k: v.detach().clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
         res.append(({k: float(v[0]) for k, v in losses.items()}, grads, bufs))

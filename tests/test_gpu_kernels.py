@@ -499,3 +499,34 @@ def test_specaugment_spans():
         if changed.any():
             assert torch.allclose(o[b][changed], mel[b].mean().expand(int(changed.sum()), M), atol=1e-5)
         assert ((o[b] != mel[b]).sum(1)[changed] >= M - 1).all()         # whole rows, never frequency columns
+
+
+@pytest.mark.parametrize("rows,V", [(300, 46), (128, 46), (5760, 46), (77, 12)])
+def test_text_head_and_loss_in_one_launch(rows, V):
+    """unast_text_head_loss (head GEMM + weighted cross-entropy + d loss / d logits from the GEMM's accumulators) against fp64 torch:
+    logits, the loss (ignore_index 0, EOS weight), and gscale * dlogits; and against the three separate launches it replaces."""
+    from unast_amd import ops
+    g = torch.Generator().manual_seed(rows + V)
+    x = torch.randn(rows, 256, generator=g); W = torch.randn(V, 256, generator=g) * 0.1; b = torch.randn(V, generator=g)
+    gold = torch.randint(0, V, (rows,), generator=g)
+    gold[::7] = 0; gold[3::11] = 2
+    eos_w, gs = 5.0, 0.5
+    ldl = (V + 3) // 4 * 4
+    xd, Wd, bd, gd = x.to(D), W.to(D), b.to(D), gold.to(D)
+    logits = torch.full((rows, ldl), float("nan"), device=D); dl = torch.full((rows, ldl), float("nan"), device=D)
+    ws = torch.zeros(8, dtype=torch.float64, device=D); loss = torch.empty(1, device=D)
+    ops.text_head_loss(xd, Wd, bd, gd, V, eos_w, gs, logits, dl, ws, loss)
+    x64 = x.double().requires_grad_(False)
+    lg = (x64 @ W.double().t() + b.double()).requires_grad_(True)
+    wvec = torch.ones(V, dtype=torch.float64); wvec[2] = eos_w
+    ref = torch.nn.functional.cross_entropy(lg, gold, weight=wvec, ignore_index=0)
+    (ref * gs).backward()
+    assert relerr(logits[:, :V], lg.detach()) < 2e-5
+    assert abs(float(loss) - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
+    assert relerr(dl[:, :V], lg.grad) < 2e-5
+    assert not torch.isnan(logits).any() and bool((dl[:, V:] == 0).all()) and bool((ws[:4] == 0).all())
+    # the three launches it replaces
+    l2 = torch.zeros(rows, ldl, device=D); ops.linear_fwd(xd, Wd, bd, l2[:, :V])
+    loss2 = torch.empty(1, device=D); ops.text_loss_fwd(l2, gd, V, eos_w, ws, loss2)
+    dl2 = torch.empty(rows, ldl, device=D); ops.text_loss_bwd(l2, gd, V, eos_w, ws, torch.tensor([gs], device=D), dl2)
+    assert relerr(logits[:, :V], l2[:, :V].cpu()) < 1e-5 and abs(float(loss) - float(loss2)) < 2e-6 and relerr(dl, dl2.cpu()) < 2e-5

@@ -112,3 +112,8 @@ DEBUG_WORKSPACES = os.environ.get("UNAST_DEBUG_WORKSPACES", "0") == "1"
 # both batches in one shape) as ONE forward and ONE backward (train.train_gen_joint_step): each encoder's stack runs once over both
 # sub-steps' batches, the frozen discriminator once over both sub-steps' encoder outputs.  0 = the two sub-steps one after the other.
 JOINT_GEN = os.environ.get("UNAST_JOINT_GEN", "1") != "0"
+
+# Heads and losses in one launch each (north_star): the text head's GEMM computes the cross-entropy and its gradient from its accumulators
+# (csrc/loss.hip text_head_loss_kernel) when the step tells the decoder call what the loss will be (decode_sequence(..., loss_hint=));
+# text_loss() then only hands the results over.  0 = head GEMM, loss forward and loss backward as three launches.
+FUSED_HEAD_LOSS = os.environ.get("UNAST_FUSED_HEAD_LOSS", "1") != "0"

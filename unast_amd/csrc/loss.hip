@@ -161,6 +161,141 @@ __global__ __launch_bounds__(256) void text_loss_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Text head + loss in ONE launch (round 4): logits = X W^T + b (TextPostnet.fc1, src/module.py:243-246, V = 46 <= 48), the weighted
+// cross-entropy of src/train.py:105-111 over them and d(loss)/d(logits), all from the head GEMM's accumulators.
+// A workgroup (8 waves) owns 128 rows; wave w multiplies its 16 rows [16 x 256] by the whole weight matrix (48 x 256, split hi/lo into a
+// swizzled LDS image once per workgroup) on the MFMA pipe, weights as the MFMA "A" operand so that a lane ends with logits of ONE row
+// (m = lane & 15) and columns 16 c + 4 g + r: the row's softmax is 12 in-lane values and two permlane swaps across the lane groups g.
+// The loss's normaliser sum(w) depends on the labels alone, so every workgroup recomputes it from `gold` first (rows x 8 bytes from
+// L2) and the gradient leaves in its final form k * w_y * (softmax - onehot), k = gscale / sum(w) -- gscale is the host's 1 / accum_steps.
+// ws as text_loss_fwd_kernel ([0] sum w * nll, [1] sum w, [3] arrivals: zero on entry, zero on exit; [4] sum w of this call).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int whl_off(int row, int col) { return row * 512 + ((((col >> 3) ^ (row & 15))) << 4) + ((col & 7) << 1); }      // [48][256] bf16, 16-B chunks XOR-ed by row
+
+__global__ __launch_bounds__(512) void text_head_loss_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, const float* __restrict__ bias,
+                                                             const int64_t* __restrict__ gold, int rows, int V, int eos_idx, float eos_weight, int pad_idx,
+                                                             float gscale, float* __restrict__ logits, float* __restrict__ dlogits, int ldl,
+                                                             double* __restrict__ ws, float* __restrict__ loss) {
+    __shared__ __attribute__((aligned(16))) unsigned char sw[2][48 * 512];
+    __shared__ float s_part[8];
+    __shared__ float s_wsum;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+    // weights -> hi / lo images (rows >= V are zero)
+    for (int i = t; i < 48 * 64; i += 512) {
+        const int n = i >> 6, c = (i & 63) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < V) v = *reinterpret_cast<const float4*>(W + (size_t)n * 256 + c);
+        u32x2 hi, lo;
+        split4<3>(v, hi, lo);
+        *reinterpret_cast<u32x2*>(sw[0] + whl_off(n, c)) = hi;
+        *reinterpret_cast<u32x2*>(sw[1] + whl_off(n, c)) = lo;
+    }
+    // sum of the label weights over ALL rows (every workgroup: it is part of every row's gradient)
+    float wl = 0.f;
+    for (int r = t; r < rows; r += 512) {
+        const int y = (int)gold[r];
+        wl += (y == pad_idx) ? 0.f : (y == eos_idx ? eos_weight : 1.f);
+    }
+    wl = wave_sum(wl);
+    if (lane == 0) s_part[wave] = wl;
+    __syncthreads();
+    if (t == 0) s_wsum = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) + ((s_part[4] + s_part[5]) + (s_part[6] + s_part[7]));
+    __syncthreads();
+    const float kg = s_wsum > 0.f ? gscale / s_wsum : 0.f;
+
+    const int m0 = blockIdx.x * 128 + wave * 16;
+    const int m = m0 + l15;
+    const bool mok = m < rows;
+    f32x4 acc[3] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    if (m0 < rows) {
+        const float* xr = X + (size_t)min(m, rows - 1) * ldx;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float4 a = *reinterpret_cast<const float4*>(xr + 32 * ks + 8 * g);
+            const float4 c = *reinterpret_cast<const float4*>(xr + 32 * ks + 8 * g + 4);
+            u32x2 h0, l0, h1, l1;
+            split4<3>(a, h0, l0);
+            split4<3>(c, h1, l1);
+            const bf16x8_t xh = __builtin_bit_cast(bf16x8_t, (u32x4){h0[0], h0[1], h1[0], h1[1]});
+            const bf16x8_t xl = __builtin_bit_cast(bf16x8_t, (u32x4){l0[0], l0[1], l1[0], l1[1]});
+#pragma unroll
+            for (int c2 = 0; c2 < 3; ++c2) {
+                const int off = whl_off(16 * c2 + l15, 32 * ks + 8 * g);
+                const bf16x8_t wh = *reinterpret_cast<const bf16x8_t*>(sw[0] + off);
+                const bf16x8_t wlo = *reinterpret_cast<const bf16x8_t*>(sw[1] + off);
+                acc[c2] = mfma16(wlo, xh, acc[c2]);
+                acc[c2] = mfma16(wh, xl, acc[c2]);
+                acc[c2] = mfma16(wh, xh, acc[c2]);
+            }
+        }
+    }
+    // lane: logits[m][16 c2 + 4 g + r]
+    float a_nll = 0.f, a_w = 0.f;
+    if (m0 < rows) {
+        const int y = mok ? (int)gold[m] : pad_idx;
+        float lg[3][4];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int c2 = 0; c2 < 3; ++c2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 16 * c2 + 4 * g + r;
+                const float v = acc[c2][r] + (n < V ? bias[n] : 0.f);
+                lg[c2][r] = v;
+                if (n < V) mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float se = 0.f, ly = 0.f;
+#pragma unroll
+        for (int c2 = 0; c2 < 3; ++c2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 16 * c2 + 4 * g + r;
+                if (n < V) se += expf(lg[c2][r] - mx);
+                if (n == y) ly = lg[c2][r];
+            }
+        se += __shfl_xor(se, 16, 64); se += __shfl_xor(se, 32, 64);
+        ly += __shfl_xor(ly, 16, 64); ly += __shfl_xor(ly, 32, 64);
+        const float wy = (y == pad_idx) ? 0.f : (y == eos_idx ? eos_weight : 1.f);
+        const float inv = 1.f / se;
+        if (mok) {
+#pragma unroll
+            for (int c2 = 0; c2 < 3; ++c2) {
+                const int n0 = 16 * c2 + 4 * g;
+                float4 lo4, dl4;
+                float* lp = &lo4.x; float* dp = &dl4.x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + r;
+                    lp[r] = n < V ? lg[c2][r] : 0.f;
+                    dp[r] = n < V ? kg * wy * (expf(lg[c2][r] - mx) * inv - (n == y ? 1.f : 0.f)) : 0.f;
+                }
+                if (n0 < ldl) {
+                    *reinterpret_cast<float4*>(logits + (size_t)m * ldl + n0) = lo4;
+                    *reinterpret_cast<float4*>(dlogits + (size_t)m * ldl + n0) = dl4;
+                }
+            }
+            if (g == 0) { a_nll = wy * (logf(se) + mx - ly); a_w = wy; }
+        }
+    }
+    double da = wave_sum_d((double)a_nll), dw = wave_sum_d((double)a_w);
+    if (lane == 0 && m0 < rows) { atomicAdd(ws + 0, da); atomicAdd(ws + 1, dw); }
+    __syncthreads();
+    if (t == 0) {
+        __threadfence();
+        const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long*>(ws + 3), 1ull) + 1ull;
+        if (arrived == gridDim.x) {
+            __threadfence();
+            const double s0 = atomicAdd(ws + 0, 0.0), s1 = atomicAdd(ws + 1, 0.0);
+            loss[0] = (float)(s0 / s1);
+            ws[4] = s1;
+            ws[0] = 0.0; ws[1] = 0.0; reinterpret_cast<unsigned long long*>(ws)[3] = 0ull;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Discriminator targets + BCE (single block; n = 2B is tiny).  target_i = (perm[i] < B ? 1-s : 1-(1-s)), flipped for
 // the generator phase (src/train.py:150-164, 319-320).
 // ------------------------------------------------------------------------------------------------------------
@@ -321,6 +456,17 @@ extern "C" int unast_scalar_combine(const float* a, const float* b, const float*
     UNAST_REQUIRE(a && out && div != 0.f, "unast_scalar_combine: bad arguments");
     hipLaunchKernelGGL(scalar_combine_kernel, dim3(1), dim3(64), 0, stream, a, b, c, div, out);
     return unast_check_launch("unast_scalar_combine");
+}
+
+extern "C" int unast_text_head_loss(const float* X, int ldx, const float* W, const float* bias, const int64_t* gold, int rows, int K, int V,
+                                    float eos_weight, float gscale, float* logits, float* dlogits, int ldl, double* ws, float* loss, hipStream_t stream) {
+    const int eos_idx = 2, pad_idx = 0;
+    UNAST_REQUIRE(X && W && bias && gold && logits && dlogits && ws && loss && rows > 0, "unast_text_head_loss: bad arguments");
+    UNAST_REQUIRE(K == 256 && V > 0 && V <= 48 && ldl >= V && ldl <= 48 && (ldl & 3) == 0 && (ldx & 3) == 0, "unast_text_head_loss: built for K = 256, V <= 48, 16-byte row strides (K=%d V=%d ldl=%d)", K, V, ldl);
+    UNAST_REQUIRE((((uintptr_t)X | (uintptr_t)W | (uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0, "unast_text_head_loss: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(text_head_loss_kernel, dim3((rows + 127) / 128), dim3(512), 0, stream, X, ldx, W, bias, gold, rows, V, eos_idx, eos_weight, pad_idx,
+                       gscale, logits, dlogits, ldl, ws, loss);
+    return unast_check_launch("unast_text_head_loss");
 }
 
 UNAST_DEFINE_RNG_EPOCH_SETTER(loss)

@@ -377,7 +377,11 @@ def text_encode_pair(cx, tape, m, ids_a, noise_a, ids_b, noise_b, lens2):
     return encoder_stack(cx, tape, x2, lens2, "text_m.encoder.transformer_encoder.layers.", a.num_layers, 2 * B, T, a.nhead, a.e_drop)
 
 
-def text_decode(cx, tape, m, ids, lens_q, mem, lens_k, Tk, shift=True):
+FUSED_STATS = {"text_head": 0, "text_grad_direct": 0, "text_grad_general": 0, "speech_head": 0, "speech_grad_direct": 0, "speech_grad_general": 0}      # launches so far (tests)
+FUSED_LOSSES = {}      # storage address of a head's output buffer -> what the fused head + loss launch left for the loss call (train.text_loss / speech_loss)
+
+
+def text_decode(cx, tape, m, ids, lens_q, mem, lens_k, Tk, shift=True, loss_hint=None):
     """TextTransformer.decode_sequence (src/network.py:483-493) incl. TextPostnet (src/module.py:233-246).
     Returns Var logits buffer [B*T, 48] (46 valid columns).  shift=False: `ids` are the decoder inputs as they are
     (TextTransformer.decode, src/network.py:446-450)."""
@@ -397,8 +401,19 @@ def text_decode(cx, tape, m, ids, lens_q, mem, lens_k, Tk, shift=True):
     W, b = cx.P["text_m.postnet.fc1.weight"], cx.P["text_m.postnet.fc1.bias"]
     V = W.shape[0]
     ldl = (V + 3) // 4 * 4
-    logits = torch.zeros(N, ldl, dtype=torch.float32, device=x.v.device)
-    ops.linear_fwd(xd, W, b, logits[:, :V])
+    if loss_hint is not None and tape is not None and E == 256 and V <= 48 and config.FUSED_HEAD_LOSS:
+        # loss_hint = (gold [B, T] int64, eos_weight, gscale, loss workspace): head GEMM, cross-entropy and its gradient in one launch
+        gold, eos_w, gscale, ws = loss_hint
+        logits = torch.empty(N, ldl, dtype=torch.float32, device=x.v.device)
+        dlogits = torch.empty(N, ldl, dtype=torch.float32, device=x.v.device)
+        loss = torch.empty(1, dtype=torch.float32, device=x.v.device)
+        goldc = gold.contiguous().view(-1)
+        ops.text_head_loss(xd, W, b, goldc, V, eos_w, gscale, logits, dlogits, ws, loss)
+        FUSED_STATS["text_head"] += 1
+        FUSED_LOSSES[logits.untyped_storage().data_ptr()] = dict(kind="text", loss=loss, dlogits=dlogits, gold=goldc, eos_weight=float(eos_w), gscale=float(gscale), ws=ws)
+    else:
+        logits = torch.zeros(N, ldl, dtype=torch.float32, device=x.v.device)
+        ops.linear_fwd(xd, W, b, logits[:, :V])
     out = Var(logits)
     if tape is not None:
         seed = cx.seed

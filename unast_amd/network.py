@@ -215,7 +215,9 @@ class TextTransformer(AutoEncoderNet):
         return (ea, (None, la, ha)), (eb, (None, lb, hb))
 
     @on_stream("text")
-    def decode_sequence(self, tgt, tgt_lens, enc_outputs, masks, teacher_ratio=1):
+    def decode_sequence(self, tgt, tgt_lens, enc_outputs, masks, teacher_ratio=1, loss_hint=None):
+        """loss_hint (not in the reference's signature; unast_amd.train passes it): (gold, eos_weight, gscale, workspace) of the text_loss call
+        that will follow on this call's logits -- the head GEMM then computes that loss and its gradient in the same launch."""
         B, T = tgt.shape
         Tk = enc_outputs.shape[1]
         lens_q = lens_i32(tgt_lens, tgt.device)
@@ -226,7 +228,7 @@ class TextTransformer(AutoEncoderNet):
 
         def run(tape, dummy, mem):
             memv = _mem_in(tape, mem, B, Tk)
-            out = F.text_decode(cx, tape, self, ids, lens_q, memv, lens_k, Tk)
+            out = F.text_decode(cx, tape, self, ids, lens_q, memv, lens_k, Tk, loss_hint=loss_hint)
             ldl = out.v.shape[1]
             o = Var(out.v.view(B, T, ldl)[..., :V])
             if tape is not None:

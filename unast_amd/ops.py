@@ -653,6 +653,12 @@ def text_loss_fwd(logits2d, gold, V, eos_weight, ws, loss):
                                     _stream()), "unast_text_loss_fwd")
 
 
+def text_head_loss(x2d, W, bias, gold, V, eos_weight, gscale, logits2d, dlogits2d, ws, loss):
+    """TextPostnet.fc1 + text_loss + its gradient with respect to the logits in one launch (csrc/loss.hip text_head_loss_kernel)."""
+    check(lib().unast_text_head_loss(_p(x2d), x2d.stride(0), _p(W), _p(bias), _p(gold), x2d.shape[0], x2d.shape[1], V, float(eos_weight), float(gscale),
+                                     _p(logits2d), _p(dlogits2d), logits2d.stride(0), _p(ws), _p(loss), _stream()), "unast_text_head_loss")
+
+
 def text_loss_bwd(logits2d, gold, V, eos_weight, ws, gscale, dlogits):
     check(lib().unast_text_loss_bwd(_p(logits2d), logits2d.stride(0), _p(gold), logits2d.shape[0], V, eos_weight, _p(ws), _p(gscale),
                                     _p(dlogits), _stream()), "unast_text_loss_bwd")

@@ -69,13 +69,14 @@ class _GoldStop:
 
 
 #####----- LOSS FUNCTIONS -----#####
-def _scalar_segment(fwd, bwd, *inputs):
-    """loss = fwd() as a 0-dim tensor; backward calls bwd(gscale_device_scalar) -> grads for `inputs`."""
+def _scalar_segment(fwd, bwd, *inputs, loss_tensor=None):
+    """loss = fwd() as a 0-dim tensor; backward calls bwd(gscale_device_scalar) -> grads for `inputs`.  loss_tensor: the [1] tensor an
+    earlier launch has already written the loss into (a fused head + loss launch)."""
     dev = inputs[0].device
     dummy = _dummy(dev)
 
     def run(tape, dmy, *ins):
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        loss = loss_tensor if loss_tensor is not None else torch.empty(1, dtype=torch.float32, device=dev)
         saved = fwd(loss)
         o = Var(loss.view(()))
         if tape is not None:
@@ -121,6 +122,14 @@ class _LossSum(torch.autograd.Function):
 _ONES = {}
 _INV = {}
 _KNOWN = {}          # data pointer of a resident constant scalar made here -> its value
+
+
+def _known_value(g):
+    """The value of an upstream-gradient scalar when it is one of the resident constants the loss sums hand down (no host read), else None."""
+    one = _ONES.get(g.device)
+    if one is not None and g.data_ptr() == one.data_ptr():
+        return 1.0
+    return _KNOWN.get(g.data_ptr())
 _WS_RING = {}
 
 
@@ -193,13 +202,22 @@ def masked_mse(gold_mel, pred_mel, mel_mask):
 
 @on_stream("text")
 def text_loss(gold_char, text_pred, eos_weight=1.0):
-    """src/train.py:105-111.  text_pred is [B, V, T] as in the reference call sites (logits.permute(0, 2, 1))."""
+    """src/train.py:105-111.  text_pred is [B, V, T] as in the reference call sites (logits.permute(0, 2, 1)).  When the decoder call that
+    produced text_pred was told about this loss (decode_sequence(..., loss_hint=), as train_gen_joint_step does), the head GEMM has
+    already computed it and its gradient (csrc/loss.hip text_head_loss_kernel); this call then launches nothing."""
     B, V, T = text_pred.shape
     gold = gold_char.to(text_pred.device).contiguous().view(-1)
     ldl = (V + 3) // 4 * 4
     lg_btv = text_pred.permute(0, 2, 1)
+    from . import functional as F
+    fused = F.FUSED_LOSSES.pop(text_pred.untyped_storage().data_ptr(), None)
+    if fused is not None and not (fused["kind"] == "text" and fused["eos_weight"] == float(eos_weight) and fused["gold"].shape == gold.shape
+                                  and (fused["gold"].data_ptr() == gold.data_ptr() or torch.equal(fused["gold"], gold))):
+        fused = None                     # another loss than the one announced: compute it the ordinary way
 
     def fwd(loss):
+        if fused is not None:
+            return None, fused["ws"]
         logits = _as_padded(lg_btv.detach(), B * T, ldl, V)
         ws = _loss_ws(loss.device)
         ops.text_loss_fwd(logits, gold, V, float(eos_weight), ws, loss)
@@ -207,9 +225,19 @@ def text_loss(gold_char, text_pred, eos_weight=1.0):
 
     def bwd(g, saved):
         logits, ws = saved
+        if fused is not None:
+            known = _known_value(g)
+            if known is not None and abs(known - fused["gscale"]) <= 1e-12 * abs(known):
+                dl = fused["dlogits"]            # already scaled by exactly this upstream gradient
+                F.FUSED_STATS["text_grad_direct"] += 1
+                return (dl.view(B, T, ldl)[..., :V].permute(0, 2, 1),)
+            F.FUSED_STATS["text_grad_general"] += 1
+            logits = _as_padded(lg_btv.detach(), B * T, ldl, V)          # another upstream gradient than announced: the general kernel
         dl = torch.empty(B * T, ldl, dtype=torch.float32, device=g.device)
         ops.text_loss_bwd(logits, gold, V, float(eos_weight), ws, g, dl)
         return (dl.view(B, T, ldl)[..., :V].permute(0, 2, 1),)
+    if fused is not None:
+        return _scalar_segment(fwd, bwd, text_pred, loss_tensor=fused["loss"])
     return _scalar_segment(fwd, bwd, text_pred)
 
 
@@ -524,10 +552,12 @@ def train_gen_joint_step(losses, model, ae_batch, sp_batch, step, accum_steps, a
         if _JOINT_D_FIRST:
             d_ae_loss, d_sp_loss = disc_losses()
         # the auto-encoder sub-step's decoders, then the supervised sub-step's (BatchNorm of the speech post-net: first ae, then tts)
-        text_pred_a = model.text_m.decode_sequence(text_a, tl_a, t_enc_a, t_masks_a).permute(0, 2, 1)
+        gs = 1.0 / float(accum_steps)          # the upstream gradient of every loss of this step (train._LossSum): the fused head + loss launches apply it
+        dev = t_enc_a.device
+        text_pred_a = model.text_m.decode_sequence(text_a, tl_a, t_enc_a, t_masks_a, loss_hint=(ya[0], args.t_eos_weight, gs, _loss_ws(dev))).permute(0, 2, 1)
         pre_a, post_a, stop_a, _ = model.speech_m.decode_sequence(mel_a, ml_a, s_enc_a, s_masks_a)
         pre_s, post_s, stop_s, _ = model.speech_m.decode_sequence(mel_s, ml_s, t_enc_s, t_masks_s)
-        text_pred_s = model.text_m.decode_sequence(text_s, tl_s, s_enc_s, s_masks_s).permute(0, 2, 1)
+        text_pred_s = model.text_m.decode_sequence(text_s, tl_s, s_enc_s, s_masks_s, loss_hint=(ys[0], args.t_eos_weight, gs, _loss_ws(dev))).permute(0, 2, 1)
         if not _JOINT_D_FIRST:
             d_ae_loss, d_sp_loss = disc_losses()
         s_ae_loss = speech_loss(ya[1], ya[2], pre_a, post_a, ml_a, stop_a, args.s_eos_weight)
