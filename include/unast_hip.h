@@ -231,6 +231,15 @@ int unast_text_loss_bwd(const float* logits, int ldl, const int64_t* gold, int r
  * gradient of the loss as the HOST knows it (1 / accum_steps in the train step); ws: as unast_text_loss_fwd. */
 int unast_text_head_loss(const float* X, int ldx, const float* W, const float* bias, const int64_t* gold, int rows, int K, int V,
                          float eos_weight, float gscale, float* logits, float* dlogits, int ldl, double* ws, float* loss, hipStream_t stream);
+/* The speech heads AND their loss terms in one launch: head[B T, ldh] = X [linear_project | stop_linear]^T + bias (M mel columns, the stop
+ * logit, zero padding; src/module.py:170-171), the pre-net masked MSE and the stop-token BCE of speech_loss (src/train.py:113-122) and
+ * d_head = gscale * d(loss)/d(head), from the head GEMM's accumulators.  ws (doubles, zero on entry) receives the two partial sums; the
+ * post-net term and the scalar follow with unast_speech_post_loss once the post-net has run (same stream): it adds
+ * sum mask (gold - post)^2, writes d_post = gscale * d(loss)/d(post), forms the loss and leaves ws zero. */
+int unast_speech_head_loss(const float* X, int ldx, const float* W, const float* bias, const float* gold, const int* lens, int B, int T, int K, int M,
+                           float eos_weight, float gscale, float* head, float* d_head, int ldh, double* ws, hipStream_t stream);
+int unast_speech_post_loss(const float* gold, const float* post, const int* lens, int B, int T, int M, float gscale, float* d_post, double* ws,
+                           float* loss, hipStream_t stream);
 /* discriminator_target (src/train.py:150-164, 319-320): smoothed labels 0.9 (text rows: perm[i] < B) / 0.1 (speech),
  * flipped (1-y) when flip=1 (generator phase). */
 int unast_disc_targets(const int64_t* perm, int n, int B, int flip, float smoothing, float* out, hipStream_t stream);

@@ -54,6 +54,7 @@ def test_joint_generator_step_equals_the_two_substeps(shape, use_disc):
         used = {k: F.FUSED_STATS[k] - before[k] for k in before}
         if joint:       # the heads computed their losses and gradients themselves, and the loss calls took those gradients as they were
             assert used["text_head"] == 2 and used["text_grad_direct"] == 2 and used["text_grad_general"] == 0, used
+            assert used["speech_head"] == 2 and used["speech_grad_direct"] == 2 and used["speech_grad_general"] == 0, used
         else:
             assert all(v == 0 for v in used.values()), used
         grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}

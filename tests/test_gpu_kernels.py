@@ -530,3 +530,45 @@ def test_text_head_and_loss_in_one_launch(rows, V):
     loss2 = torch.empty(1, device=D); ops.text_loss_fwd(l2, gd, V, eos_w, ws, loss2)
     dl2 = torch.empty(rows, ldl, device=D); ops.text_loss_bwd(l2, gd, V, eos_w, ws, torch.tensor([gs], device=D), dl2)
     assert relerr(logits[:, :V], l2[:, :V].cpu()) < 1e-5 and abs(float(loss) - float(loss2)) < 2e-6 and relerr(dl, dl2.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("B,T", [(3, 50), (2, 128), (32, 800)])
+def test_speech_heads_and_loss_terms_in_two_launches(B, T):
+    """unast_speech_head_loss (head GEMM + pre-net MSE + stop BCE + d loss / d head) followed by unast_speech_post_loss (post-net MSE,
+    d loss / d post, the scalar) against the three launches they replace (head GEMM, speech_loss_fwd, speech_loss_bwd) and, at the small
+    sizes, against fp64 torch."""
+    from unast_amd import ops
+    M, ldh = 80, 84
+    g = torch.Generator().manual_seed(B * T)
+    N = B * T
+    x = torch.randn(N, 256, generator=g); W = torch.randn(M + 1, 256, generator=g) * 0.1; b = torch.randn(M + 1, generator=g)
+    gold = torch.rand(B, T, M, generator=g); post = torch.rand(B, T, M, generator=g)
+    lens = torch.randint(1, T + 1, (B,), generator=g).to(torch.int32); lens[0] = T
+    eos_w, gs = 5.0, 0.5
+    xd, Wd, bd, gd, pd, ld = x.to(D), W.to(D), b.to(D), gold.to(D), post.to(D), lens.to(D)
+    head = torch.full((N, ldh), float("nan"), device=D); dh = torch.full((N, ldh), float("nan"), device=D)
+    ws = torch.zeros(8, dtype=torch.float64, device=D); loss = torch.empty(1, device=D); dp = torch.full((B, T, M), float("nan"), device=D)
+    ops.speech_head_loss(xd, Wd, bd, gd.view(N, M), ld, B, T, M, eos_w, gs, head, dh, ws)
+    ops.speech_post_loss(gd.view(N, M), pd.view(N, M), ld, B, T, M, gs, dp, ws, loss)
+    h2 = torch.zeros(N, ldh, device=D); ops.linear_fwd(xd, Wd, bd, h2[:, :M + 1])
+    loss2 = torch.empty(1, device=D); ops.speech_loss_fwd(gd, h2.view(B, T, ldh), pd, ld, eos_w, ws, loss2)
+    dh2 = torch.empty(B, T, ldh, device=D); dp2 = torch.empty(B, T, M, device=D)
+    ops.speech_loss_bwd(gd, h2.view(B, T, ldh), pd, ld, eos_w, torch.tensor([gs], device=D), dh2, dp2)
+    assert relerr(head[:, :M + 1], h2[:, :M + 1].cpu()) < 1e-5 and bool((head[:, M + 1:] == 0).all())
+    assert abs(float(loss) - float(loss2)) < 3e-6 * max(1.0, abs(float(loss2)))
+    assert relerr(dh, dh2.view(N, ldh).cpu()) < 2e-5 and relerr(dp, dp2.cpu()) < 1e-6 and bool((ws[:4] == 0).all())
+    if N <= 300:
+        x64, W64 = x.double(), W.double()
+        hh = (x64 @ W64.t() + b.double()).requires_grad_(True)
+        p64 = post.double().requires_grad_(True)
+        mask = (torch.arange(T)[None, :] < lens[:, None]).double()[..., None]
+        pre = hh[:, :M].view(B, T, M)
+        denom = mask.sum() * M
+        y = torch.nn.functional.one_hot(lens.long() - 1, T).double()
+        pw = 1.0 + (eos_w - 1.0) * y
+        st = hh[:, M].view(B, T)
+        bce = ((1 - y) * st + pw * (torch.log1p(torch.exp(-st.abs())) + torch.clamp(-st, min=0))).mean()
+        ref = ((gold.double() - pre) ** 2 * mask).sum() / denom + ((gold.double() - p64) ** 2 * mask).sum() / denom + bce
+        (ref * gs).backward()
+        assert abs(float(loss) - ref.item()) < 3e-6 * max(1.0, abs(ref.item()))
+        assert relerr(dh[:, :M + 1], hh.grad) < 3e-5 and relerr(dp, p64.grad) < 1e-5

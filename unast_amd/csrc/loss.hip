@@ -296,6 +296,161 @@ __global__ __launch_bounds__(512) void text_head_loss_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Speech heads + their loss terms in ONE launch (round 4): head[rows, 84] = X [linear_project | stop_linear]^T + b (80 mel columns and the
+// stop logit, src/module.py:170-171), the pre-net masked MSE and the stop-token BCE of speech_loss (src/train.py:113-122) and
+// d(loss)/d(head), from the head GEMM's accumulators; same fragment layout as text_head_loss_kernel with six 16-column tiles.
+// The third term of the loss -- the post-net MSE -- needs the post-net's output, which does not exist yet: speech_post_loss_kernel
+// below adds it, writes d(loss)/d(post) and finishes the scalar.  ws (doubles, zero on entry): [0] sum mask (gold - pre)^2, [2] sum bce;
+// nothing is finalised here.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void speech_head_loss_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, const float* __restrict__ bias,
+                                                               const float* __restrict__ gold, const int* __restrict__ lens, int B, int T, int M,
+                                                               float eos_weight, float gscale, float* __restrict__ head, float* __restrict__ d_head, int ldh,
+                                                               double* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sdyn[];          // [2][96 * 512]: hi / lo images of the 81 x 256 weights (rows >= 81 zero)
+    unsigned char* sw0 = sdyn;
+    unsigned char* sw1 = sdyn + 96 * 512;
+    __shared__ float s_denom;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+    const int rows = B * T, NO = M + 1;
+    for (int i = t; i < 96 * 64; i += 512) {
+        const int n = i >> 6, c = (i & 63) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < NO) v = *reinterpret_cast<const float4*>(W + (size_t)n * 256 + c);
+        u32x2 hi, lo;
+        split4<3>(v, hi, lo);
+        *reinterpret_cast<u32x2*>(sw0 + whl_off(n, c)) = hi;
+        *reinterpret_cast<u32x2*>(sw1 + whl_off(n, c)) = lo;
+    }
+    if (t == 0) {
+        double sl = 0.0;
+        for (int b = 0; b < B; ++b) sl += (double)lens[b];
+        s_denom = (float)(sl * (double)M);
+    }
+    __syncthreads();
+    const float km = 2.f * gscale / s_denom, ks = gscale / (float)rows;
+    const int m0 = blockIdx.x * 128 + wave * 16;
+    const int m = m0 + l15;
+    const bool mok = m < rows;
+    f32x4 acc[6];
+#pragma unroll
+    for (int c2 = 0; c2 < 6; ++c2) acc[c2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float a0 = 0.f, a2 = 0.f;
+    if (m0 < rows) {
+        const float* xr = X + (size_t)min(m, rows - 1) * ldx;
+#pragma unroll
+        for (int ks8 = 0; ks8 < 8; ++ks8) {
+            const float4 a = *reinterpret_cast<const float4*>(xr + 32 * ks8 + 8 * g);
+            const float4 c = *reinterpret_cast<const float4*>(xr + 32 * ks8 + 8 * g + 4);
+            u32x2 h0, l0, h1, l1;
+            split4<3>(a, h0, l0);
+            split4<3>(c, h1, l1);
+            const bf16x8_t xh = __builtin_bit_cast(bf16x8_t, (u32x4){h0[0], h0[1], h1[0], h1[1]});
+            const bf16x8_t xl = __builtin_bit_cast(bf16x8_t, (u32x4){l0[0], l0[1], l1[0], l1[1]});
+#pragma unroll
+            for (int c2 = 0; c2 < 6; ++c2) {
+                const int off = whl_off(16 * c2 + l15, 32 * ks8 + 8 * g);
+                const bf16x8_t wh = *reinterpret_cast<const bf16x8_t*>(sw0 + off);
+                const bf16x8_t wlo = *reinterpret_cast<const bf16x8_t*>(sw1 + off);
+                acc[c2] = mfma16(wlo, xh, acc[c2]);
+                acc[c2] = mfma16(wh, xl, acc[c2]);
+                acc[c2] = mfma16(wh, xh, acc[c2]);
+            }
+        }
+        if (mok) {
+            const int b = m / T, tt = m - b * T;
+            const int len = lens[b];
+            const bool live = tt < len;
+#pragma unroll
+            for (int c2 = 0; c2 < 6; ++c2) {
+                const int n0 = 16 * c2 + 4 * g;
+                if (n0 >= ldh) continue;
+                float4 hv = make_float4(0.f, 0.f, 0.f, 0.f), dv = hv;
+                float* hp = &hv.x; float* dp = &dv.x;
+                if (n0 < M) {                                        // four mel columns (M % 4 == 0)
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias + n0);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                    float gd[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (live) { const float4 g4 = *reinterpret_cast<const float4*>(gold + (size_t)m * M + n0); gd[0] = g4.x; gd[1] = g4.y; gd[2] = g4.z; gd[3] = g4.w; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = acc[c2][r] + bb[r];
+                        hp[r] = p;
+                        if (live) { const float d = p - gd[r]; a0 += d * d; dp[r] = km * d; }
+                    }
+                } else if (n0 == M) {                                // the stop logit, then zero padding
+                    const float x = acc[c2][0] + bias[M];
+                    const float y = (tt == len - 1) ? 1.f : 0.f;
+                    const float lw = 1.f + (eos_weight - 1.f) * y;
+                    hp[0] = x;
+                    a2 += (1.f - y) * x + lw * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f));
+                    dp[0] = ks * ((1.f - y) - lw * (1.f - 1.f / (1.f + expf(-x))));
+                }
+                *reinterpret_cast<float4*>(head + (size_t)m * ldh + n0) = hv;
+                *reinterpret_cast<float4*>(d_head + (size_t)m * ldh + n0) = dv;
+            }
+        }
+    }
+    __shared__ double red[8][2];
+    const double d0 = wave_sum_d((double)a0), d2 = wave_sum_d((double)a2);
+    if (lane == 0) { red[wave][0] = d0; red[wave][1] = d2; }
+    __syncthreads();
+    if (t < 2) {
+        double v = 0.0;
+        for (int w = 0; w < 8; ++w) v += red[w][t];
+        atomicAdd(ws + (t == 0 ? 0 : 2), v);
+    }
+}
+
+// The post-net term: sum mask (gold - post)^2 into ws[1], d(loss)/d(post) = gscale * 2 (post - gold) mask / denom, and -- last workgroup to
+// arrive -- the scalar: (ws[0] + ws[1]) / denom + ws[2] / (B T), with ws[0] and ws[2] left by speech_head_loss_kernel earlier on this stream;
+// ws is zero again on exit ([3]: arrival counter).
+__global__ __launch_bounds__(256) void speech_post_loss_kernel(const float* __restrict__ gold, const float* __restrict__ post, const int* __restrict__ lens,
+                                                               int B, int T, int M, float gscale, float* __restrict__ d_post, double* __restrict__ ws,
+                                                               float* __restrict__ loss) {
+    __shared__ float s_denom;
+    if (threadIdx.x == 0) {
+        double sl = 0.0;
+        for (int b = 0; b < B; ++b) sl += (double)lens[b];
+        s_denom = (float)(sl * (double)M);
+    }
+    __syncthreads();
+    const float km = 2.f * gscale / s_denom;
+    const int rows = B * T, mq = M >> 2;
+    const size_t total = (size_t)rows * mq;
+    float a1 = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / mq), c = (int)(i - (size_t)r * mq) * 4;
+        const int b = r / T, t = r - b * T;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < lens[b]) {
+            const float4 g = *reinterpret_cast<const float4*>(gold + (size_t)r * M + c);
+            const float4 q = *reinterpret_cast<const float4*>(post + (size_t)r * M + c);
+            const float dx = q.x - g.x, dy = q.y - g.y, dz = q.z - g.z, dw = q.w - g.w;
+            a1 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            o = make_float4(km * dx, km * dy, km * dz, km * dw);
+        }
+        *reinterpret_cast<float4*>(d_post + (size_t)r * M + c) = o;
+    }
+    __shared__ double red[4];
+    const double d1 = wave_sum_d((double)a1);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(ws + 1, (red[0] + red[1]) + (red[2] + red[3]));
+        __threadfence();
+        const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long*>(ws + 3), 1ull) + 1ull;
+        if (arrived == gridDim.x) {
+            __threadfence();
+            const double s0 = atomicAdd(ws + 0, 0.0), s1 = atomicAdd(ws + 1, 0.0), s2 = atomicAdd(ws + 2, 0.0);
+            const double denom = (double)s_denom;
+            loss[0] = (float)(s0 / denom + s1 / denom + s2 / ((double)B * T));
+            ws[0] = 0.0; ws[1] = 0.0; ws[2] = 0.0; reinterpret_cast<unsigned long long*>(ws)[3] = 0ull;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Discriminator targets + BCE (single block; n = 2B is tiny).  target_i = (perm[i] < B ? 1-s : 1-(1-s)), flipped for
 // the generator phase (src/train.py:150-164, 319-320).
 // ------------------------------------------------------------------------------------------------------------
@@ -467,6 +622,27 @@ extern "C" int unast_text_head_loss(const float* X, int ldx, const float* W, con
     hipLaunchKernelGGL(text_head_loss_kernel, dim3((rows + 127) / 128), dim3(512), 0, stream, X, ldx, W, bias, gold, rows, V, eos_idx, eos_weight, pad_idx,
                        gscale, logits, dlogits, ldl, ws, loss);
     return unast_check_launch("unast_text_head_loss");
+}
+
+extern "C" int unast_speech_head_loss(const float* X, int ldx, const float* W, const float* bias, const float* gold, const int* lens, int B, int T, int K, int M,
+                                      float eos_weight, float gscale, float* head, float* d_head, int ldh, double* ws, hipStream_t stream) {
+    UNAST_REQUIRE(X && W && bias && gold && lens && head && d_head && ws && B > 0 && T > 0, "unast_speech_head_loss: bad arguments");
+    UNAST_REQUIRE(K == 256 && M > 0 && (M & 3) == 0 && M + 1 <= 96 && ldh >= M + 1 && ldh <= 96 && (ldh & 3) == 0 && (ldx & 3) == 0,
+                  "unast_speech_head_loss: built for K = 256, M %% 4 == 0, M + 1 <= 96 (K=%d M=%d ldh=%d)", K, M, ldh);
+    UNAST_REQUIRE((((uintptr_t)X | (uintptr_t)W | (uintptr_t)bias | (uintptr_t)gold | (uintptr_t)head | (uintptr_t)d_head) & 15) == 0, "unast_speech_head_loss: operands must be 16-byte aligned");
+    static bool attr = [] { return hipFuncSetAttribute((const void*)speech_head_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 96 * 512) == hipSuccess; }();
+    (void)attr;
+    const int rows = B * T;
+    hipLaunchKernelGGL(speech_head_loss_kernel, dim3((rows + 127) / 128), dim3(512), 2 * 96 * 512, stream, X, ldx, W, bias, gold, lens, B, T, M, eos_weight, gscale,
+                       head, d_head, ldh, ws);
+    return unast_check_launch("unast_speech_head_loss");
+}
+
+extern "C" int unast_speech_post_loss(const float* gold, const float* post, const int* lens, int B, int T, int M, float gscale, float* d_post, double* ws,
+                                      float* loss, hipStream_t stream) {
+    UNAST_REQUIRE(gold && post && lens && d_post && ws && loss && B > 0 && T > 0 && M > 0 && (M & 3) == 0, "unast_speech_post_loss: bad arguments");
+    hipLaunchKernelGGL(speech_post_loss_kernel, dim3(ls_grid((size_t)B * T * (M / 4))), dim3(256), 0, stream, gold, post, lens, B, T, M, gscale, d_post, ws, loss);
+    return unast_check_launch("unast_speech_post_loss");
 }
 
 UNAST_DEFINE_RNG_EPOCH_SETTER(loss)

@@ -502,7 +502,7 @@ def speech_encode_pair(cx, tape, m, mel_a, noise_a, mel_b, noise_b, lens2):
     return encoder_stack(cx, tape, x2, lens2, "speech_m.encoder.transformer_encoder.layers.", a.num_layers, 2 * B, T, a.nhead, a.e_drop)
 
 
-def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk, shift=True, postnet=True):
+def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk, shift=True, postnet=True, loss_hint=None):
     """SpeechTransformer.decode_sequence (src/network.py:254-269) + SpeechPostnet (src/module.py:155-171).
     Returns (head Var [B*T, 84]: cols 0..79 pre-net mel, col 80 stop logit; post Var [B*T, 80]).
     shift=False feeds `mel` as the decoder input as it is, postnet=False stops at the heads (SpeechTransformer.decode,
@@ -525,8 +525,21 @@ def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk, shift=True, postnet
     Wh = st.span("speech_m.postnet.linear_project.weight", "speech_m.postnet.stop_linear.weight", (M + 1, E))
     bh = st.span("speech_m.postnet.linear_project.bias", "speech_m.postnet.stop_linear.bias", (M + 1,))
     ldh = (M + 1 + 3) // 4 * 4
-    head = torch.zeros(N, ldh, dtype=torch.float32, device=mel.device)
-    ops.linear_fwd(x.v, Wh, bh, head[:, :M + 1])
+    fused = None
+    if loss_hint is not None and tape is not None and postnet and E == 256 and M % 4 == 0 and M + 1 <= 96 and config.FUSED_HEAD_LOSS and \
+            Wh.data_ptr() % 16 == 0 and bh.data_ptr() % 16 == 0:
+        # loss_hint = (gold mel [B, T, M], lengths int32 [B], eos_weight, gscale, loss workspace): the heads, the pre-net MSE, the stop BCE and
+        # their gradient in one launch; the post-net term and the scalar follow behind the post-net (speech_post_loss below)
+        gold, glens, eos_w, gscale, ws = loss_hint
+        goldc = gold.contiguous()
+        head = torch.empty(N, ldh, dtype=torch.float32, device=mel.device)
+        d_head = torch.empty(N, ldh, dtype=torch.float32, device=mel.device)
+        ops.speech_head_loss(x.v, Wh, bh, goldc.view(N, M), glens, B, T, M, eos_w, gscale, head, d_head, ws)
+        FUSED_STATS["speech_head"] += 1
+        fused = dict(kind="speech", gold=goldc, lens=glens, eos_weight=float(eos_w), gscale=float(gscale), ws=ws, d_head=d_head)
+    else:
+        head = torch.zeros(N, ldh, dtype=torch.float32, device=mel.device)
+        ops.linear_fwd(x.v, Wh, bh, head[:, :M + 1])
     headv = Var(head)
     pre = Var(head)                                                 # postnet input = columns [0,M) of head (row stride ldh)
     postv = Var(None)
@@ -559,6 +572,11 @@ def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk, shift=True, postnet
     C = y.v.shape[1]
     ops.gemm(ops.OP_KC_CONV, ops.OP_KC, y.v, C, Wp2, 5 * C, post, M, N, M, 5 * C, conv=(T, C, 0, 4), bias=b2, R=head, ldr=ldh)   # + residual pre
     postv.v = post.view(N, M)
+    if fused is not None:
+        fused["d_post"] = torch.empty(B, T, M, dtype=torch.float32, device=mel.device)
+        fused["loss"] = torch.empty(1, dtype=torch.float32, device=mel.device)
+        ops.speech_post_loss(fused["gold"].view(N, M), postv.v, fused["lens"], B, T, M, fused["gscale"], fused["d_post"], fused["ws"], fused["loss"])
+        FUSED_LOSSES[head.untyped_storage().data_ptr()] = fused
     if tape is not None:
         def bwd_conv2():
             if postv.g is None:

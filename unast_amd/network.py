@@ -327,7 +327,9 @@ class SpeechTransformer(AutoEncoderNet):
         return (ea, (None, la, ha)), (eb, (None, lb, hb))
 
     @on_stream("speech")
-    def decode_sequence(self, tgt, tgt_lens, enc_outputs, masks, teacher_ratio=1):
+    def decode_sequence(self, tgt, tgt_lens, enc_outputs, masks, teacher_ratio=1, loss_hint=None):
+        """loss_hint (not in the reference's signature): (gold mel, lengths, eos_weight, gscale, workspace) of the speech_loss call that will
+        follow on this call's outputs -- the head GEMM then computes the pre-net and stop terms and their gradient in the same launch."""
         B, T, M = tgt.shape
         Tk = enc_outputs.shape[1]
         lens_q = lens_i32(tgt_lens, tgt.device)
@@ -337,7 +339,7 @@ class SpeechTransformer(AutoEncoderNet):
 
         def run(tape, dummy, mem):
             memv = _mem_in(tape, mem, B, Tk)
-            head, post = F.speech_decode(cx, tape, self, mel, lens_q, memv, lens_k, Tk)
+            head, post = F.speech_decode(cx, tape, self, mel, lens_q, memv, lens_k, Tk, loss_hint=loss_hint)
             ldh = head.v.shape[1]
             h3 = head.v.view(B, T, ldh)
             o_pre, o_post, o_stop = Var(h3[..., :M]), Var(post.v.view(B, T, M)), Var(h3[..., M])

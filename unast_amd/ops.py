@@ -659,6 +659,17 @@ def text_head_loss(x2d, W, bias, gold, V, eos_weight, gscale, logits2d, dlogits2
                                      _p(logits2d), _p(dlogits2d), logits2d.stride(0), _p(ws), _p(loss), _stream()), "unast_text_head_loss")
 
 
+def speech_head_loss(x2d, W, bias, gold2d, lens, B, T, M, eos_weight, gscale, head, d_head, ws):
+    """[linear_project | stop_linear] + the pre-net MSE and stop BCE of speech_loss + their gradient in one launch (csrc/loss.hip)."""
+    check(lib().unast_speech_head_loss(_p(x2d), x2d.stride(0), _p(W), _p(bias), _p(gold2d), _p(lens), B, T, x2d.shape[1], M, float(eos_weight), float(gscale),
+                                       _p(head), _p(d_head), head.stride(0), _p(ws), _stream()), "unast_speech_head_loss")
+
+
+def speech_post_loss(gold2d, post2d, lens, B, T, M, gscale, d_post, ws, loss):
+    """The post-net MSE term, its gradient and the finished speech_loss scalar (after speech_head_loss on the same stream)."""
+    check(lib().unast_speech_post_loss(_p(gold2d), _p(post2d), _p(lens), B, T, M, float(gscale), _p(d_post), _p(ws), _p(loss), _stream()), "unast_speech_post_loss")
+
+
 def text_loss_bwd(logits2d, gold, V, eos_weight, ws, gscale, dlogits):
     check(lib().unast_text_loss_bwd(_p(logits2d), logits2d.stride(0), _p(gold), logits2d.shape[0], V, eos_weight, _p(ws), _p(gscale),
                                     _p(dlogits), _stream()), "unast_text_loss_bwd")

@@ -251,15 +251,26 @@ def speech_loss(gold_mel, stop_label, pred_mel, post_pred_mel, mel_len, stop_pre
     if stop_pred.dim() == 3:
         stop_pred = stop_pred.squeeze(-1)
 
-    def fwd(loss):
-        pm, sp = pred_mel.detach(), stop_pred.detach()
+    from . import functional as F
+    fused = F.FUSED_LOSSES.pop(pred_mel.untyped_storage().data_ptr(), None)
+    if fused is not None and not (fused["kind"] == "speech" and fused["eos_weight"] == float(eos_weight) and fused["gold"].shape == gold.shape
+                                  and (fused["gold"].data_ptr() == gold.data_ptr() or torch.equal(fused["gold"], gold))
+                                  and (fused["lens"].data_ptr() == lens.data_ptr() or torch.equal(fused["lens"], lens))):
+        fused = None                     # another loss than the one announced to decode_sequence(loss_hint=): the ordinary way
+
+    def head_of(pm, sp):
         if pm.stride(-1) == 1 and pm.stride(-2) == ldh and sp.data_ptr() == pm.data_ptr() + 4 * M and sp.stride(-1) == ldh \
                 and pm.stride(0) == T * ldh:
-            head = pm.as_strided((B * T, ldh), (ldh, 1))
-        else:
-            head = torch.zeros(B * T, ldh, dtype=torch.float32, device=pm.device)
-            head[:, :M].copy_(pm.reshape(B * T, M))
-            head[:, M].copy_(sp.reshape(B * T))
+            return pm.as_strided((B * T, ldh), (ldh, 1))
+        head = torch.zeros(B * T, ldh, dtype=torch.float32, device=pm.device)
+        head[:, :M].copy_(pm.reshape(B * T, M))
+        head[:, M].copy_(sp.reshape(B * T))
+        return head
+
+    def fwd(loss):
+        if fused is not None:            # the head launch and speech_post_loss have computed everything (csrc/loss.hip)
+            return None, None
+        head = head_of(pred_mel.detach(), stop_pred.detach())
         post = post_pred_mel.detach().contiguous()
         ws = _loss_ws(loss.device)
         ops.speech_loss_fwd(gold, head.view(B, T, ldh), post, lens, float(eos_weight), ws, loss)
@@ -267,10 +278,21 @@ def speech_loss(gold_mel, stop_label, pred_mel, post_pred_mel, mel_len, stop_pre
 
     def bwd(g, saved):
         head, post = saved
+        if fused is not None:
+            known = _known_value(g)
+            if known is not None and abs(known - fused["gscale"]) <= 1e-12 * abs(known):
+                F.FUSED_STATS["speech_grad_direct"] += 1
+                dh = fused["d_head"].view(B, T, ldh)
+                return dh[..., :M], fused["d_post"], dh[..., M]
+            F.FUSED_STATS["speech_grad_general"] += 1
+            head = head_of(pred_mel.detach(), stop_pred.detach())
+            post = post_pred_mel.detach().contiguous()
         dh = torch.empty(B, T, ldh, dtype=torch.float32, device=g.device)
         dp = torch.empty(B, T, M, dtype=torch.float32, device=g.device)
         ops.speech_loss_bwd(gold, head.view(B, T, ldh), post, lens, float(eos_weight), g, dh, dp)
         return dh[..., :M], dp, dh[..., M]
+    if fused is not None:
+        return _scalar_segment(fwd, bwd, pred_mel, post_pred_mel, stop_pred, loss_tensor=fused["loss"])
     return _scalar_segment(fwd, bwd, pred_mel, post_pred_mel, stop_pred)
 
 
@@ -555,8 +577,8 @@ def train_gen_joint_step(losses, model, ae_batch, sp_batch, step, accum_steps, a
         gs = 1.0 / float(accum_steps)          # the upstream gradient of every loss of this step (train._LossSum): the fused head + loss launches apply it
         dev = t_enc_a.device
         text_pred_a = model.text_m.decode_sequence(text_a, tl_a, t_enc_a, t_masks_a, loss_hint=(ya[0], args.t_eos_weight, gs, _loss_ws(dev))).permute(0, 2, 1)
-        pre_a, post_a, stop_a, _ = model.speech_m.decode_sequence(mel_a, ml_a, s_enc_a, s_masks_a)
-        pre_s, post_s, stop_s, _ = model.speech_m.decode_sequence(mel_s, ml_s, t_enc_s, t_masks_s)
+        pre_a, post_a, stop_a, _ = model.speech_m.decode_sequence(mel_a, ml_a, s_enc_a, s_masks_a, loss_hint=(ya[1], ml_a, args.s_eos_weight, gs, _loss_ws(dev)))
+        pre_s, post_s, stop_s, _ = model.speech_m.decode_sequence(mel_s, ml_s, t_enc_s, t_masks_s, loss_hint=(ys[1], ml_s, args.s_eos_weight, gs, _loss_ws(dev)))
         text_pred_s = model.text_m.decode_sequence(text_s, tl_s, s_enc_s, s_masks_s, loss_hint=(ys[0], args.t_eos_weight, gs, _loss_ws(dev))).permute(0, 2, 1)
         if not _JOINT_D_FIRST:
             d_ae_loss, d_sp_loss = disc_losses()
