@@ -439,7 +439,7 @@ def main():
     gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0
     gtf = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
     traffic = None
-    for tp in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for tp in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         tp = os.path.join(ROOT, "profiles", tp)
         if a.workload == "c3" and config.NSPLIT == 3 and os.path.exists(tp):
             try:
@@ -450,7 +450,7 @@ def main():
             except Exception:
                 traffic = None
     rocprof_avg = None           # the same family's average launch duration in the committed single-stream rocprofv3 summary
-    for cp in ("r03_b_bench_c3_single_stream_kernel_stats.csv", "r02_f_bench_c3_single_stream_kernel_stats.csv", "r02_d_bench_c3_single_stream_kernel_stats.csv"):
+    for cp in ("r04_b_bench_c3_single_stream_kernel_stats.csv", "r03_b_bench_c3_single_stream_kernel_stats.csv", "r02_f_bench_c3_single_stream_kernel_stats.csv"):
         cp = os.path.join(ROOT, "profiles", cp)
         if a.workload == "c3" and config.NSPLIT == 3 and os.path.exists(cp):
             try:
@@ -475,7 +475,7 @@ def main():
                         "timed region (inside the timed region a launch shares the chip with the kernels of the other three streams, and a replayed "
                         "capture has no per-kernel host hooks); traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE per launch "
                         "from profiles/ (separate rocprofv3 passes of this command), null if absent; rocprof_avg_launch_us = the family's average kernel "
-                        "duration in the committed single-stream rocprofv3 summary (profiles/r03_b_* or the newest older one; profiles_match_csrc says whether csrc/ still is what that summary was taken from): avg_launch_us brackets each launch with a "
+                        "duration in the committed single-stream rocprofv3 summary (profiles/r04_b_* or the newest older one; profiles_match_csrc says whether csrc/ still is what that summary was taken from): avg_launch_us brackets each launch with a "
                         "HIP-event pair and so carries ~4 us of dispatch per launch on top of it; mfma_view / attn_*: 2MNK FLOPs per "
                         "contraction, 4*B*H*Tq*Tk*64 per attention forward (x2.5 backward, causal at T(T+1)/2); each product costs %d bf16 MFMAs in "
                         "%s mode; sustained MFMA peak = tools/mfma_peak.cpp on this chip" % (config.NSPLIT, a.precision)}

@@ -278,7 +278,7 @@ def test_lru_keeps_the_hot_shape_while_cold_ones_pass_through(monkeypatch):
 
 def test_mutual_waits_between_side_streams_are_refused_inside_a_capture():
     """ROCm 7.2's hipStreamEndCapture crashes (inside the runtime) when two streams forked from the capture's origin wait on each other
-    (A waits for B after B waited for A: tools/debug_capture2.py T1).  The package never builds that topology and its wait helper refuses
+    (A waits for B after B waited for A: tools/debug_capture.py T1).  The package never builds that topology and its wait helper refuses
     it with a Python error while the capture is still open -- exactly that topology here, through engine.wait; one-way waits and waits
     through the origin stay legal, and outside a capture nothing is checked."""
     from unast_amd import engine

@@ -400,6 +400,10 @@ __global__ __launch_bounds__(128 * (4 / QS), (QS == 1 ? 4 : 2)) void attn_q_kern
 // [key][d] image of V deliver.  The running maximum is only raised when some query's tile maximum exceeds it by more than 8 (in log2
 // units: P <= 256, exact in fp32 and in the hi/lo split), so the rescaling pass over the 32 output accumulators leaves the loop.
 // Same masks, same dropout decisions (rng_pair over adjacent keys) and the same three-term products as the 16x16x32 kernel.
+// Measured and removed again (round 4; git history has it): the two 32-key halves of a tile software-pipelined inside the wave -- online
+// softmax per half, dropout as a template parameter so that an interior iteration is one basic block, sched_group_barrier pinning one
+// MFMA of S(h+1) / P.V(h-1) per ~22 vector instructions of softmax(h), which hipcc did emit -- ran 97 vs 92 us at 800 x 800 with dropout
+// (103 vs 108 without): interleaving the two instruction kinds inside a wave buys nothing over what the SIMD's second wave already covers.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 __device__ __forceinline__ f32x16 mfma32(const bf16x8_t& a, const bf16x8_t& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);

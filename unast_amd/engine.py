@@ -128,7 +128,7 @@ def join_streams():
 
 class _CaptureWaits:
     """Waits between streams placed by this package while a HIP graph is being captured.  ROCm 7.2's hipStreamEndCapture dies (a
-    segmentation fault inside the runtime, tools/debug_capture2.py T1 / T6 / T10) when two streams that are both forked from the capture's
+    segmentation fault inside the runtime, tools/debug_capture.py T1 / T6 / T10) when two streams that are both forked from the capture's
     origin wait on EACH OTHER -- A waits for B after B has waited for A; one-way waits (T9) and waits through the origin (T3) are fine.
     The cause inside the runtime is not known; the package therefore never builds that topology (on_stream hands tensors side -> origin
     -> side, _ViaOrigin makes autograd do the same, ddp._issue leaves marker nodes without events), and every explicit wait goes through
@@ -169,7 +169,7 @@ _FORCE_VIA_ORIGIN = _os.environ.get("UNAST_VIA_ORIGIN", "0") == "1"      # exper
 class _ViaOrigin(torch.autograd.Function):
     """Identity placed -- on the CALLER's stream -- on an edge between two side streams while a HIP graph is being captured.
     ROCm 7.2's hipStreamEndCapture crashes when a side stream waits on an event of another side stream that has itself waited
-    on the first one (A -> B -> A; tools/debug_capture2.py T1/T6 crash, T3 "via origin" and T9 "one way" do not), and the train
+    on the first one (A -> B -> A; tools/debug_capture.py T1/T6 crash, T3 "via origin" and T9 "one way" do not), and the train
     step has such pairs: text encoder -> speech decoder in the forward, speech decoder -> text encoder in the backward.  With
     this node in between, torch's autograd hands the gradient side -> origin -> side, and on_stream does the same for the
     forward value, so side streams only ever wait on the origin stream."""

@@ -145,7 +145,7 @@ def _alias(tape, var):
     torch's autograd graph and THIS call's backward adds the two incoming gradients itself (on its own stream, after autograd
     has ordered it behind both producers).  Letting autograd sum gradients that arrive from different streams in a node's
     input buffer works eagerly but takes hipStreamEndCapture down when the step is captured into a HIP graph (ROCm 7.2;
-    tools/debug_capture.py cases aedisc_* vs discdetach_ms), and the encoder output has two users on two streams: the
+    the round-2 capture probe, cases aedisc_* vs discdetach_ms, in the git history), and the encoder output has two users on two streams: the
     decoder (cross-attention memory) and the discriminator."""
     o = Var(var.v.view(var.v.shape))
     if tape is not None:

@@ -109,7 +109,7 @@ def _splitk_for(M, N, K):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     ksteps = (K + 31) // 32
     # every split writes and re-reads an [M,N] slab: for a small gradient (<= 4 tiles) one workgroup per CU is the optimum, a
-    # larger one amortises the slabs over more operand bytes and gains from two per CU (tools/bench_wgrad.py: 768x256 over
+    # larger one amortises the slabs over more operand bytes and gains from two per CU (round-1 tools/bench_wgrad.py: 768x256 over
     # 25600 tokens 76 -> 57 us at 42 instead of 21 splits; 256x256 39.7 us at 64 splits, 53.7 at 128)
     target = SPLITK_TARGET_BLOCKS * (2 if tiles >= 8 else 1)
     want = max(1, target // tiles)
