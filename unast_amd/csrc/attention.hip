@@ -530,19 +530,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
 #endif
         if (wave_live) {
         f32x16 s[2];
+        // Every K fragment of the tile is requested from LDS BEFORE the first MFMA (16 ds_read_b128, 64 VGPRs that are free in this phase):
+        // left to itself hipcc placed each read right in front of the one or two MFMAs that use it, with an s_waitcnt in between -- the full
+        // LDS latency in front of every MFMA pair, and the S product at half the matrix pipe's rate (the knock-out builds priced 24 MFMAs
+        // at 30 us of a 114-us launch; the pipe needs 15).  The empty asm pins the order: its operands must all have arrived.
+        bf16x8_t kfh[2][4], kfl[2][4];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int kst = 0; kst < 4; ++kst) {
+                const int off = kimg_off(32 * t2 + n, 16 * kst + 8 * hi);
+                kfh[t2][kst] = *reinterpret_cast<const bf16x8_t*>(sK[0] + off);
+                kfl[t2][kst] = (PARTS == 2) ? *reinterpret_cast<const bf16x8_t*>(sK[PARTS - 1] + off) : kfh[t2][kst];
+            }
+        asm volatile("" : "+v"(kfh[0][0]), "+v"(kfh[0][1]), "+v"(kfh[0][2]), "+v"(kfh[0][3]), "+v"(kfh[1][0]), "+v"(kfh[1][1]), "+v"(kfh[1][2]), "+v"(kfh[1][3]));
+        if (PARTS == 2) asm volatile("" : "+v"(kfl[0][0]), "+v"(kfl[0][1]), "+v"(kfl[0][2]), "+v"(kfl[0][3]), "+v"(kfl[1][0]), "+v"(kfl[1][1]), "+v"(kfl[1][2]), "+v"(kfl[1][3]));
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[t2][i] = 0.f;
 #pragma unroll
             for (int kst = 0; kst < 4; ++kst) {
-                const int off = kimg_off(32 * t2 + n, 16 * kst + 8 * hi);
-                const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(sK[0] + off);
-                const bf16x8_t kl = (PARTS == 2) ? *reinterpret_cast<const bf16x8_t*>(sK[PARTS - 1] + off) : kh;
 #ifdef KO_SMFMA
-                s[t2][kst] += __builtin_bit_cast(f32x4, kh)[0] + __builtin_bit_cast(f32x4, kl)[1];
+                s[t2][kst] += __builtin_bit_cast(f32x4, kfh[t2][kst])[0] + __builtin_bit_cast(f32x4, kfl[t2][kst])[1];
 #else
-                s[t2] = mma3_32<NSPLIT>(kh, kl, qf[kst][0], qf[kst][PARTS - 1], s[t2]);
+                s[t2] = mma3_32<NSPLIT>(kfh[t2][kst], kfl[t2][kst], qf[kst][0], qf[kst][PARTS - 1], s[t2]);
 #endif
             }
         }
@@ -598,24 +610,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
 #ifndef KO_SOFTMAX
         if (interior) softmax_tile(std::false_type{}); else softmax_tile(std::true_type{});
 #endif
+        // the same for the V fragments, one 32-key half ahead of its MFMAs (16 transposed reads = 32 VGPRs per half)
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
+        for (int t2 = 0; t2 < 2; ++t2) {
+            bf16x8_t vfh[2][2], vfl[2][2];
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                bf16x8_t ph, pl;
-                split8<NSPLIT>(make_float4(s[t2][8 * v], s[t2][8 * v + 1], s[t2][8 * v + 2], s[t2][8 * v + 3]),
-                               make_float4(s[t2][8 * v + 4], s[t2][8 * v + 5], s[t2][8 * v + 6], s[t2][8 * v + 7]), ph, pl);
+            for (int v = 0; v < 2; ++v)
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x8_t xh = vtr_frag32(sV[0], 32 * t2 + 16 * v, 32 * dt, lane);
-                    const bf16x8_t xl = (PARTS == 2) ? vtr_frag32(sV[PARTS - 1], 32 * t2 + 16 * v, 32 * dt, lane) : xh;
+                    vfh[v][dt] = vtr_frag32(sV[0], 32 * t2 + 16 * v, 32 * dt, lane);
+                    vfl[v][dt] = (PARTS == 2) ? vtr_frag32(sV[PARTS - 1], 32 * t2 + 16 * v, 32 * dt, lane) : vfh[v][dt];
+                }
+            bf16x8_t ph[2], pl[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+                split8<NSPLIT>(make_float4(s[t2][8 * v], s[t2][8 * v + 1], s[t2][8 * v + 2], s[t2][8 * v + 3]),
+                               make_float4(s[t2][8 * v + 4], s[t2][8 * v + 5], s[t2][8 * v + 6], s[t2][8 * v + 7]), ph[v], pl[v]);
+            asm volatile("" : "+v"(vfh[0][0]), "+v"(vfh[0][1]), "+v"(vfh[1][0]), "+v"(vfh[1][1]));
+            if (PARTS == 2) asm volatile("" : "+v"(vfl[0][0]), "+v"(vfl[0][1]), "+v"(vfl[1][0]), "+v"(vfl[1][1]));
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
 #ifdef KO_PVMFMA
-                    o[dt][2 * t2 + v] += __builtin_bit_cast(f32x4, xh)[0] + __builtin_bit_cast(f32x4, xl)[1] + __builtin_bit_cast(f32x4, ph)[0] + __builtin_bit_cast(f32x4, pl)[1];
+                    o[dt][2 * t2 + v] += __builtin_bit_cast(f32x4, vfh[v][dt])[0] + __builtin_bit_cast(f32x4, vfl[v][dt])[1] + __builtin_bit_cast(f32x4, ph[v])[0] + __builtin_bit_cast(f32x4, pl[v])[1];
 #else
-                    o[dt] = mma3_32<NSPLIT>(xh, xl, ph, pl, o[dt]);
+                    o[dt] = mma3_32<NSPLIT>(vfh[v][dt], vfl[v][dt], ph[v], pl[v], o[dt]);
 #endif
                 }
-            }
+        }
         }   // wave_live
 #ifndef KO_BARRIER
         __syncthreads();
