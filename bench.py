@@ -468,7 +468,7 @@ def main():
                 "rocprof_avg_launch_us": rocprof_avg, "profiles_match_csrc": profiles_fresh(),
                 "mfma_view": {"achieved_tflops": round(gtf, 2), "frac_of_2500_dense_bf16": round(gtf / PEAK_MFMA_BF16_TFLOPS, 4),
                               "mfma_issue_tflops": round(gtf * config.NSPLIT, 1), "sustained_mfma_peak_measured_tflops": SUSTAINED_MFMA_TFLOPS},
-                "attn_fwd": mfma_entry("attn_fwd", "attn_q_kernel<%d,0>" % config.NSPLIT),
+                "attn_fwd": mfma_entry("attn_fwd", "attn_fwd32_kernel<%d> (32x32x16 MFMA tiles)" % config.NSPLIT),
                 "attn_bwd": mfma_entry("attn_bwd", ATTN_BWD_KERNEL % {"n": config.NSPLIT}),
                 "note": "dominant family = GEMM.  achieved = algorithmic bytes (fp32 A + B + C and epilogue operands, each once; conv inputs once, not "
                         "per tap) / HIP-event time of these launches, taken on the launch stream in the isolated single-stream steps after the "

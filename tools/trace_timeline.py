@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(f)))
 qk = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"
 short = lambda n: n.replace("void ", "").split("(")[0][:40]
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[qk], short(r["Kernel_Name"])) for r in rows)
-marks = [x[0] for x in iv if x[3].startswith("set_words_kernel")]
+marks = [x[0] for x in iv if x[3].startswith("set_words_kernel")] or [x[0] for x in iv if x[3].startswith("specaugment_sum")]
 lo, hi = (marks[-back - 1], marks[-back]) if len(marks) > back + 1 else (iv[len(iv) // 2][0], iv[-1][1])
 iv = [x for x in iv if lo <= x[0] < hi]
 span = hi - lo

@@ -117,3 +117,7 @@ JOINT_GEN = os.environ.get("UNAST_JOINT_GEN", "1") != "0"
 # (csrc/loss.hip text_head_loss_kernel) when the step tells the decoder call what the loss will be (decode_sequence(..., loss_hint=));
 # text_loss() then only hands the results over.  0 = head GEMM, loss forward and loss backward as three launches.
 FUSED_HEAD_LOSS = os.environ.get("UNAST_FUSED_HEAD_LOSS", "1") != "0"
+
+# ... and the two speech decoder calls of the joint generator step as one (SpeechTransformer.decode_pair): self-attention and feed-forward
+# over both sub-steps' targets, cross-attention per call.  0 = two decode_sequence calls.
+JOINT_DECODERS = os.environ.get("UNAST_JOINT_DECODERS", "1") != "0"

@@ -140,6 +140,128 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
     return out
 
 
+def cross_attn_sublayer_pair(cx, tape, x2, mems, lens_ks, Tks, pre_attn, pre_norm, B, Tq, H, drop):
+    """The cross-attention sub-layer of TWO decoder calls of one query shape and the same weights (the auto-encoder and the supervised
+    sub-step's decoder, /root/reference/src/train.py:609-628): y = LN(x + dropout(MHA(x, mem_h))) for the two row blocks of x2 [2 B Tq, E]
+    with their own memories mems[h] (Var [B Tk_h, E]).  Everything that does not see the memory runs once over both blocks -- the query
+    projection, the out-projection + LayerNorm, their backward GEMMs and weight gradients; the K/V projections and the attention core
+    run per block."""
+    E = x2.v.shape[1]
+    N = B * Tq
+    W, bias = cx.P[pre_attn + "in_proj_weight"], cx.P[pre_attn + "in_proj_bias"]
+    Wo, bo = cx.P[pre_attn + "out_proj.weight"], cx.P[pre_attn + "out_proj.bias"]
+    p = cx.p(drop)
+    s_attn, s_out = (cx.stream(), cx.stream()), cx.stream()
+    ps = config.ATTN_PRESPLIT
+    q2 = _empty(2 * N, E, like=x2.v)
+    ops.linear_fwd(x2.v, W[:E], bias[:E], q2, out_split=ps)
+    kvs = []
+    for h in range(2):
+        kv = _empty(B * Tks[h], 2 * E, like=x2.v)
+        ops.linear_fwd(mems[h].v, W[E:], bias[E:], kv, out_split=ps)
+        kvs.append(kv)
+    O2 = _empty(2 * N, E, like=x2.v)
+    LSE2 = _empty(2, B, H, Tq, like=x2.v)
+    for h in range(2):
+        ops.attn_fwd(q2[h * N:(h + 1) * N], kvs[h][:, :E], kvs[h][:, E:], O2[h * N:(h + 1) * N], LSE2[h], lens_ks[h], B, H, Tq, Tks[h], False,
+                     drop_p=p, seed=cx.seed, stream_id=s_attn[h], qkv_split=ps)
+    z = _empty(2 * N, E, like=x2.v)
+    y, mean, rstd = _empty(2 * N, E, like=x2.v), _empty(2 * N, like=x2.v), _empty(2 * N, like=x2.v)
+    ops.linear_fwd(O2, Wo, bo, z, drop_p=p, seed=cx.seed, stream_id=s_out, R=x2.v, ln=(cx.P[pre_norm + "weight"], cx.P[pre_norm + "bias"], y, mean, rstd, LN_EPS))
+    out = Var(y)
+    if tape is not None:
+        seed = cx.seed
+
+        def bwd():
+            if out.g is None:
+                return
+            with ops.wgrad_batch():
+                st = cx.st
+                dz = _empty(2 * N, E, like=z)
+                dzd = _empty(2 * N, E, like=z) if p > 0 else None
+                ops.layernorm_bwd(out.g, z, cx.P[pre_norm + "weight"], mean, rstd, dz, dzd, st.g(pre_norm + "weight"), st.g(pre_norm + "bias"),
+                                  drop_p=p, seed=seed, stream_id=s_out)
+                da = dzd if p > 0 else dz
+                gWo = st.g(pre_attn + "out_proj.weight")
+                if gWo is not None:
+                    ops.linear_wgrad(da, O2, gWo, db=st.g(pre_attn + "out_proj.bias"))
+                dO = _empty(2 * N, E, like=z)
+                ops.linear_dgrad(da, Wo, dO, out_split=ps)
+                gW, gb = st.g(pre_attn + "in_proj_weight"), st.g(pre_attn + "in_proj_bias")
+                dq2 = _empty(2 * N, E, like=z)
+                dkvs = []
+                for h in range(2):
+                    delta = _empty(B, H, Tq, like=z)
+                    dkv = _empty(B * Tks[h], 2 * E, like=z)
+                    ops.attn_bwd(q2[h * N:(h + 1) * N], kvs[h][:, :E], kvs[h][:, E:], O2[h * N:(h + 1) * N], dO[h * N:(h + 1) * N], LSE2[h], delta,
+                                 dq2[h * N:(h + 1) * N], dkv[:, :E], dkv[:, E:], lens_ks[h], B, H, Tq, Tks[h], False,
+                                 drop_p=p, seed=seed, stream_id=s_attn[h], qkv_split=ps)
+                    dkvs.append(dkv)
+                    dmem = _empty(B * Tks[h], E, like=z)
+                    ops.linear_dgrad(dkv, W[E:], dmem)
+                    acc(mems[h], dmem)
+                if gW is not None:
+                    ops.linear_wgrad(dkvs[0], mems[0].v, gW[E:], db=gb[E:])
+                    ops.linear_wgrad(dq2, x2.v, gW[:E], db=gb[:E])
+                dx = _empty(2 * N, E, like=z)
+                ops.linear_dgrad(dq2, W[:E], dx, R=dz)
+                acc(x2, dx)
+            # the second memory's K/V weight gradient accumulates into the SAME rows of in_proj_weight as the first's: the problems of a
+            # grouped launch run side by side, so it goes out on its own, behind the group (same stream: ops keeps a gradient buffer's stream)
+            gW = cx.st.g(pre_attn + "in_proj_weight")
+            if gW is not None:
+                ops.linear_wgrad(dkvs[1], mems[1].v, gW[E:], db=cx.st.g(pre_attn + "in_proj_bias")[E:])
+        tape.record(bwd)
+    return out
+
+
+def decoder_stack_pair(cx, tape, x2, lens_q2, mems, lens_ks, Tks, pre, L, B, Tq, H, drop):
+    """decoder_stack over two calls of one query shape at once: causal self-attention and the feed-forward block over 2B sequences, the
+    cross-attention per call on its own memory (cross_attn_sublayer_pair)."""
+    for i in range(L):
+        lp = "%s%d." % (pre, i)
+        x2 = attn_sublayer(cx, tape, x2, None, lens_q2, True, lp + "self_attn.", lp + "norm1.", 2 * B, Tq, Tq, H, drop)
+        x2 = cross_attn_sublayer_pair(cx, tape, x2, mems, lens_ks, Tks, lp + "multihead_attn.", lp + "norm2.", B, Tq, H, drop)
+        x2 = ffn_sublayer(cx, tape, x2, lp, lp + "norm3.", drop)
+    return x2
+
+
+def speech_decode_pair(cx, tape, m, mels, lens_q2, mems, lens_ks, Tks, loss_hints):
+    """SpeechTransformer.decode_sequence of TWO calls of one target shape (the auto-encoder's and the TTS decoder of one generator phase):
+    front ends per call into one buffer, the decoder stack once over both (decoder_stack_pair), heads + post-net + loss terms per call
+    (the post-net's BatchNorm statistics stay per call, first a, then b).  Returns [(head Var, post Var)] per call."""
+    B, T, M = mels[0].shape
+    a = m.args
+    N = B * T
+    E = cx.P["speech_m.prenet.layer.fc2.linear_layer.weight"].shape[0]
+    buf = _empty(2 * N, E, like=mels[0])
+    halves = [speech_decode_front(cx, tape, m, mels[h], True, out=buf[h * N:(h + 1) * N]) for h in range(2)]
+    x2 = _stack_rows(cx, tape, halves, buf)
+    y2 = decoder_stack_pair(cx, tape, x2, lens_q2, mems, lens_ks, Tks, "speech_m.decoder.transformer_decoder.layers.", a.num_layers, B, T, a.nhead, a.d_drop)
+    # the two tails read row blocks of y2 and put their d(loss)/dx straight into row blocks of ONE gradient buffer
+    gbuf = {}
+    xs = [Var(y2.v[h * N:(h + 1) * N]) for h in range(2)]
+    if tape is not None:
+        def join():                                   # recorded before the tails => runs after them: hand the buffer to the stack
+            if "g" in gbuf:
+                for h in range(2):
+                    if xs[h].g is None:
+                        gbuf["g"][h * N:(h + 1) * N].zero_()
+                    elif xs[h].g.data_ptr() != gbuf["g"][h * N:(h + 1) * N].data_ptr():
+                        ops.sum2(gbuf["g"][h * N:(h + 1) * N], xs[h].g.contiguous())
+                acc(y2, gbuf["g"])
+        tape.record(join)
+
+    def dx_block(h):
+        def get():
+            if "g" not in gbuf:
+                gbuf["g"] = _empty(2 * N, E, like=y2.v)
+            return gbuf["g"][h * N:(h + 1) * N]
+        return get
+    outs = [speech_decode_tail(cx, tape, m, xs[h], mels[h], postnet=True, loss_hint=loss_hints[h], dx_out=dx_block(h)) for h in range(2)]
+    return outs
+
+
 def ffn_sublayer(cx, tape, x, pre, pre_norm, drop):
     """y = LN(x + dropout(W2 dropout(relu(W1 x + b1)) + b2))."""
     N, E = x.v.shape
@@ -502,13 +624,9 @@ def speech_encode_pair(cx, tape, m, mel_a, noise_a, mel_b, noise_b, lens2):
     return encoder_stack(cx, tape, x2, lens2, "speech_m.encoder.transformer_encoder.layers.", a.num_layers, 2 * B, T, a.nhead, a.e_drop)
 
 
-def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk, shift=True, postnet=True, loss_hint=None):
-    """SpeechTransformer.decode_sequence (src/network.py:254-269) + SpeechPostnet (src/module.py:155-171).
-    Returns (head Var [B*T, 84]: cols 0..79 pre-net mel, col 80 stop logit; post Var [B*T, 80]).
-    shift=False feeds `mel` as the decoder input as it is, postnet=False stops at the heads (SpeechTransformer.decode,
-    src/network.py:210-214; no tape)."""
+def speech_decode_front(cx, tape, m, mel, shift=True, out=None):
+    """The decoder input of SpeechTransformer.decode_sequence: go-frame shift (src/network.py:254-262), SpeechPrenet, positional encoding."""
     B, T, M = mel.shape
-    a = m.args
     N = B * T
     if shift:
         if M % 4 == 0 and mel.is_contiguous() and mel.data_ptr() % 16 == 0:
@@ -518,8 +636,27 @@ def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk, shift=True, postnet
             tgt[:, 1:] = mel[:, :-1]
     else:
         tgt = mel.contiguous()
-    x = speech_prenet(cx, tape, m, tgt.view(N, M), T)
+    return speech_prenet(cx, tape, m, tgt.view(N, M), T, out=out)
+
+
+def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk, shift=True, postnet=True, loss_hint=None):
+    """SpeechTransformer.decode_sequence (src/network.py:254-269) + SpeechPostnet (src/module.py:155-171).
+    Returns (head Var [B*T, 84]: cols 0..79 pre-net mel, col 80 stop logit; post Var [B*T, 80]).
+    shift=False feeds `mel` as the decoder input as it is, postnet=False stops at the heads (SpeechTransformer.decode,
+    src/network.py:210-214; no tape)."""
+    B, T, M = mel.shape
+    a = m.args
+    x = speech_decode_front(cx, tape, m, mel, shift)
     x = decoder_stack(cx, tape, x, lens_q, mem, lens_k, "speech_m.decoder.transformer_decoder.layers.", a.num_layers, B, T, Tk, a.nhead, a.d_drop)
+    return speech_decode_tail(cx, tape, m, x, mel, postnet=postnet, loss_hint=loss_hint)
+
+
+def speech_decode_tail(cx, tape, m, x, mel, postnet=True, loss_hint=None, dx_out=None):
+    """The heads ([linear_project | stop_linear]) and the SpeechPostnet on decoder states x (Var [B*T, E]); mel only gives shapes / device.
+    dx_out: where the backward puts d(loss)/dx (a row block of a paired call's gradient buffer) instead of a buffer of its own."""
+    B, T, M = mel.shape
+    a = m.args
+    N = B * T
     E = x.v.shape[1]
     st = cx.st
     Wh = st.span("speech_m.postnet.linear_project.weight", "speech_m.postnet.stop_linear.weight", (M + 1, E))
@@ -556,7 +693,7 @@ def speech_decode(cx, tape, m, mel, lens_q, mem, lens_k, Tk, shift=True, postnet
             gW = st.gspan("speech_m.postnet.linear_project.weight", "speech_m.postnet.stop_linear.weight", (M + 1, E))
             if gW is not None:
                 ops.linear_wgrad(dh[:, :M + 1], x.v, gW, db=st.gspan("speech_m.postnet.linear_project.bias", "speech_m.postnet.stop_linear.bias", (M + 1,)))
-            dx = _empty(N, E, like=x.v)
+            dx = dx_out() if dx_out is not None else _empty(N, E, like=x.v)
             ops.linear_dgrad(dh[:, :M + 1], Wh, dx)
             acc(x, dx)
         tape.record(bwd_head)                                       # runs after every postnet closure

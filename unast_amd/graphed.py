@@ -91,7 +91,7 @@ class GraphedTrainStep:
         shp = lambda k, n: tuple((k, i, tuple(tuple(t.shape) for t in batches[k][i])) for i in range(n))
         gen = shp("unsup", a.ae_steps) + shp("sup", a.sp_steps)
         disc = shp("disc", a.d_steps) if a.use_discriminator else ()
-        return gen, disc, (is_deterministic(), config.NSPLIT, self.model.training, config.JOINT_GEN)
+        return gen, disc, (is_deterministic(), config.NSPLIT, self.model.training, config.JOINT_GEN, config.JOINT_DECODERS)
 
     @staticmethod
     def _static_like(batch, dev):

@@ -164,6 +164,33 @@ def _mem_in(tape, mem, B, Tk):
     return memv
 
 
+def _speech_outputs(tape, head, post, B, T, M, device):
+    """(pre, post, stop) output Vars of a speech decoder call over its head buffer [B T, ldh] and post-net output [B T, M]; their closure
+    (recorded last => runs first) turns the three incoming gradients back into d(head) and d(post)."""
+    ldh = head.v.shape[1]
+    h3 = head.v.view(B, T, ldh)
+    o_pre, o_post, o_stop = Var(h3[..., :M]), Var(post.v.view(B, T, M)), Var(h3[..., M])
+    if tape is not None:
+        def bwd():
+            if o_post.g is not None:
+                post.g = (o_post.g if o_post.g.is_contiguous() else o_post.g.contiguous()).view(B * T, M)
+            gp, gs = o_pre.g, o_stop.g
+            if gp is None and gs is None:
+                return
+            if gp is not None and gs is not None and gp.stride(-1) == 1 and gp.stride(-2) == ldh and \
+                    gs.data_ptr() == gp.data_ptr() + 4 * M and gs.stride(-1) == ldh:
+                head.g = gp.as_strided((B * T, ldh), (ldh, 1))          # both are views of one d_head buffer
+            else:
+                buf = torch.zeros(B * T, ldh, dtype=torch.float32, device=device)
+                if gp is not None:
+                    buf[:, :M].copy_(gp.reshape(B * T, M))
+                if gs is not None:
+                    buf[:, M].copy_(gs.reshape(B * T))
+                head.g = buf
+        tape.record(bwd)
+    return [o_pre, o_post, o_stop]
+
+
 class TextTransformer(AutoEncoderNet):
     """src/network.py:417-500."""
     _prefix = "text_m."
@@ -340,30 +367,34 @@ class SpeechTransformer(AutoEncoderNet):
         def run(tape, dummy, mem):
             memv = _mem_in(tape, mem, B, Tk)
             head, post = F.speech_decode(cx, tape, self, mel, lens_q, memv, lens_k, Tk, loss_hint=loss_hint)
-            ldh = head.v.shape[1]
-            h3 = head.v.view(B, T, ldh)
-            o_pre, o_post, o_stop = Var(h3[..., :M]), Var(post.v.view(B, T, M)), Var(h3[..., M])
-            if tape is not None:
-                def bwd():
-                    if o_post.g is not None:
-                        post.g = (o_post.g if o_post.g.is_contiguous() else o_post.g.contiguous()).view(B * T, M)
-                    gp, gs = o_pre.g, o_stop.g
-                    if gp is None and gs is None:
-                        return
-                    if gp is not None and gs is not None and gp.stride(-1) == 1 and gp.stride(-2) == ldh and \
-                            gs.data_ptr() == gp.data_ptr() + 4 * M and gs.stride(-1) == ldh:
-                        head.g = gp.as_strided((B * T, ldh), (ldh, 1))          # both are views of one d_head buffer
-                    else:
-                        buf = torch.zeros(B * T, ldh, dtype=torch.float32, device=mel.device)
-                        if gp is not None:
-                            buf[:, :M].copy_(gp.reshape(B * T, M))
-                        if gs is not None:
-                            buf[:, M].copy_(gs.reshape(B * T))
-                        head.g = buf
-                tape.record(bwd)                                                    # runs first
-            return [o_pre, o_post, o_stop]
+            return _speech_outputs(tape, head, post, B, T, M, mel.device)
         pre, post, stop = run_segment(run, ddp_hook("speech_dec", cx.st), cx.st.dummy, enc_outputs)
         return pre, post, stop, tgt_lens
+
+    @on_stream("speech")
+    def decode_pair(self, tgt_a, lens_a, enc_a, masks_a, hint_a, tgt_b, lens_b, enc_b, masks_b, hint_b):
+        """decode_sequence(tgt_a, lens_a, enc_a, masks_a) and decode_sequence(tgt_b, lens_b, enc_b, masks_b) of two targets of ONE shape as
+        a single call: the decoder stack runs once over both (self-attention and feed-forward over 2B sequences, cross-attention per call on
+        its own memory), front ends, heads, post-net (BatchNorm statistics: first a, then b) and loss terms per call
+        (unast_amd.functional.speech_decode_pair).  Returns the two (pre, post, stop, lens) tuples of the separate calls."""
+        if tgt_a.shape != tgt_b.shape:
+            raise ValueError("decode_pair: the two targets must have one shape")
+        B, T, M = tgt_a.shape
+        Tks = (enc_a.shape[1], enc_b.shape[1])
+        lq = torch.cat([lens_i32(lens_a, tgt_a.device), lens_i32(lens_b, tgt_b.device)])
+        lens_ks = (masks_a[1], masks_b[1])
+        cx = self._ctx()
+        mels = (tgt_a.detach().contiguous(), tgt_b.detach().contiguous())
+
+        def run(tape, dummy, mem_a, mem_b):
+            mems = (_mem_in(tape, mem_a, B, Tks[0]), _mem_in(tape, mem_b, B, Tks[1]))
+            outs = F.speech_decode_pair(cx, tape, self, mels, lq, mems, lens_ks, Tks, (hint_a, hint_b))
+            res = []
+            for (head, post) in outs:
+                res += _speech_outputs(tape, head, post, B, T, M, mels[0].device)
+            return res
+        pa, qa, sa, pb, qb, sb = run_segment(run, ddp_hook("speech_dec", cx.st), cx.st.dummy, enc_a, enc_b)
+        return (pa, qa, sa, lens_a), (pb, qb, sb, lens_b)
 
     @on_stream("speech")
     def decode(self, tgt, tgt_lens, tgt_pad_mask, enc_outputs, enc_mask):

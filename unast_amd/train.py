@@ -548,6 +548,7 @@ def train_gen_joint_step(losses, model, ae_batch, sp_batch, step, accum_steps, a
     frozen LSTM discriminator scores both sub-steps' encoder outputs in one call (4B sequences: 256 workgroups per recurrent launch
     instead of 128, 8 launches per step instead of 12), and the two sub-steps' decoders are independent work on two streams.
     Needs both batches in one shape; otherwise (or with config.JOINT_GEN off) the caller runs the two sub-steps one after the other."""
+    from . import config
     (xa, ya), (xs, ys) = process_batch(ae_batch), process_batch(sp_batch)
     text_a, mel_a, tl_a, ml_a = xa
     text_s, mel_s, tl_s, ml_s = xs
@@ -577,8 +578,14 @@ def train_gen_joint_step(losses, model, ae_batch, sp_batch, step, accum_steps, a
         gs = 1.0 / float(accum_steps)          # the upstream gradient of every loss of this step (train._LossSum): the fused head + loss launches apply it
         dev = t_enc_a.device
         text_pred_a = model.text_m.decode_sequence(text_a, tl_a, t_enc_a, t_masks_a, loss_hint=(ya[0], args.t_eos_weight, gs, _loss_ws(dev))).permute(0, 2, 1)
-        pre_a, post_a, stop_a, _ = model.speech_m.decode_sequence(mel_a, ml_a, s_enc_a, s_masks_a, loss_hint=(ya[1], ml_a, args.s_eos_weight, gs, _loss_ws(dev)))
-        pre_s, post_s, stop_s, _ = model.speech_m.decode_sequence(mel_s, ml_s, t_enc_s, t_masks_s, loss_hint=(ys[1], ml_s, args.s_eos_weight, gs, _loss_ws(dev)))
+        hint_a, hint_s = (ya[1], ml_a, args.s_eos_weight, gs, _loss_ws(dev)), (ys[1], ml_s, args.s_eos_weight, gs, _loss_ws(dev))
+        if config.JOINT_DECODERS and mel_a.shape == mel_s.shape:
+            # the auto-encoder's speech decoder and the TTS decoder as one call: the stack once over both, cross-attention per call
+            (pre_a, post_a, stop_a, _), (pre_s, post_s, stop_s, _) = model.speech_m.decode_pair(mel_a, ml_a, s_enc_a, s_masks_a, hint_a,
+                                                                                                 mel_s, ml_s, t_enc_s, t_masks_s, hint_s)
+        else:
+            pre_a, post_a, stop_a, _ = model.speech_m.decode_sequence(mel_a, ml_a, s_enc_a, s_masks_a, loss_hint=hint_a)
+            pre_s, post_s, stop_s, _ = model.speech_m.decode_sequence(mel_s, ml_s, t_enc_s, t_masks_s, loss_hint=hint_s)
         text_pred_s = model.text_m.decode_sequence(text_s, tl_s, s_enc_s, s_masks_s, loss_hint=(ys[0], args.t_eos_weight, gs, _loss_ws(dev))).permute(0, 2, 1)
         if not _JOINT_D_FIRST:
             d_ae_loss, d_sp_loss = disc_losses()
