@@ -52,9 +52,15 @@ static bool simulate(int n, const std::vector<std::vector<int>>& deps, int nstre
     return true;
 }
 
+static void run_case_mode(const char* name, int n, const std::vector<std::vector<int>>& deps, int nstreams, int max_cross, bool keep_chains);
 static void run_case(const char* name, int n, const std::vector<std::vector<int>>& deps, int nstreams, int max_cross = -1) {
+    run_case_mode(name, n, deps, nstreams, max_cross, false);
+    run_case_mode(name, n, deps, nstreams, max_cross, true);          // the shipped policy (graph_exec.cpp): streams kept for the longer chain at a fork
+}
+
+static void run_case_mode(const char* name, int n, const std::vector<std::vector<int>>& deps, int nstreams, int max_cross, bool keep_chains) {
     Layout lay; std::string err, why;
-    const bool ok = plan_layout(n, deps, nstreams, lay, err);
+    const bool ok = plan_layout(n, deps, nstreams, lay, err, keep_chains);
     CHECK(ok, "%s: plan_layout failed: %s", name, err.c_str());
     if (!ok) return;
     CHECK(simulate(n, deps, nstreams, lay, why), "%s (%d streams): %s", name, nstreams, why.c_str());
@@ -85,6 +91,17 @@ int main() {
       const int j = 1 + nb * len; for (int b = 0; b < nb; ++b) d[j].push_back(b * len + len);
       for (int i = 1; i < 20; ++i) d[j + i] = {j + i - 1};
       run_case("train-step", n, d, 4); run_case("train-step", n, d, 2); run_case("train-step", n, d, 1, 0); }
+    // keep_chains: a backward-like chain whose every node forks a short side branch (a weight gradient) issued BEFORE the chain's next
+    // node: the chain must stay on ONE stream (no event on it), the side work goes elsewhere
+    { const int len = 60, n = 1 + 2 * len + 1; std::vector<std::vector<int>> d(n);       // node 0, then per step: side (2i+1), chain (2i+2); sink joins everything
+      for (int i = 0; i < len; ++i) { const int prev = i ? 2 * i : 0; d[2 * i + 1] = {prev}; d[2 * i + 2] = {prev}; }
+      for (int i = 0; i < len; ++i) d[n - 1].push_back(2 * i + 1);
+      d[n - 1].push_back(2 * len);
+      Layout lay; std::string err; CHECK(plan_layout(n, d, 4, lay, err, true), "fork-chain: %s", err.c_str());
+      int chain_stream = -1; bool one = true;
+      for (const LayoutOp& op : lay.ops) if (op.kind == L_NODE && op.id > 0 && op.id < n - 3 /* the last step's two nodes are equally far from the sink: a tie */ && op.id % 2 == 0) { if (chain_stream < 0) chain_stream = op.stream; one = one && op.stream == chain_stream; }
+      CHECK(one, "fork-chain: the chain hops streams under keep_chains");
+      run_case("fork-chain", n, d, 4); run_case("fork-chain", n, d, 2); }
     // independent nodes only
     { std::vector<std::vector<int>> d(9); run_case("independent", 9, d, 3, 0); }
     // random DAGs (duplicate dependencies included: the capture can list one twice)

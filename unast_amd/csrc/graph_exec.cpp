@@ -14,6 +14,7 @@
 // makes plan creation fail with an error string; the caller then falls back to hipGraphLaunch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <map>
@@ -81,7 +82,8 @@ extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
     unast_layout::Layout lay;
     {
         std::string err;
-        if (!unast_layout::plan_layout((int)n, deps, nstreams, lay, err)) { unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: %s", err.c_str()); return 0; }
+        static const bool keep_chains = [] { const char* e = getenv("UNAST_REPLAY_KEEP_CHAINS"); return !(e && e[0] == '0'); }();
+        if (!unast_layout::plan_layout((int)n, deps, nstreams, lay, err, keep_chains)) { unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: %s", err.c_str()); return 0; }
     }
     Plan* plan = new Plan();
     plan->events.assign(lay.event_node.size(), nullptr);

@@ -6,6 +6,10 @@
 // behind every node some other stream waits for.  A node continues the stream of a dependency that is still that stream's tail (the
 // newest such), otherwise it opens a branch on a stream that is empty, whose branch has ended (its tail has no unplaced successors),
 // or -- failing both -- the least recently used one.
+// keep_chains (round 4): at a fork the stream goes to the successor with the LONGEST way still ahead of it (in nodes, to a sink); a
+// shorter-lived successor that happens to come first in the order -- a weight gradient issued in front of the input gradient that
+// continues the backward chain -- opens the branch instead.  Without it the long dependent chain of a step hops streams at every such
+// fork (one event hand-off each) and the side work takes over the stream its producer ran on.
 #pragma once
 #include <algorithm>
 #include <functional>
@@ -28,7 +32,7 @@ struct Layout {
     int cross_edges = 0;
 };
 
-inline bool plan_layout(int n, const std::vector<std::vector<int>>& deps, int nstreams, Layout& out, std::string& err) {
+inline bool plan_layout(int n, const std::vector<std::vector<int>>& deps, int nstreams, Layout& out, std::string& err, bool keep_chains = false) {
     out = Layout();
     if (n <= 0 || nstreams < 1 || (int)deps.size() != n) { err = "bad arguments"; return false; }
     std::vector<std::vector<int>> succ(n);
@@ -51,6 +55,13 @@ inline bool plan_layout(int n, const std::vector<std::vector<int>>& deps, int ns
         }
         if ((int)order.size() != n) { err = "graph has a cycle"; return false; }
     }
+    // way[v]: nodes on the longest path from v to a sink (v included)
+    std::vector<int> way(n, 1);
+    if (keep_chains)
+        for (int oi = n - 1; oi >= 0; --oi) {
+            const int v = order[oi];
+            for (int s : succ[v]) way[v] = std::max(way[v], way[s] + 1);
+        }
     std::vector<int> stream_of(n, -1), tail(nstreams, -1), remaining(n), event_of(n, -1), pos_in_order(n, 0);
     std::vector<long long> last_use(nstreams, -1);
     for (int i = 0; i < n; ++i) remaining[i] = (int)succ[i].size();
@@ -64,7 +75,13 @@ inline bool plan_layout(int n, const std::vector<std::vector<int>>& deps, int ns
         int s = -1, best = -1;
         for (int d : deps[v]) {
             const int sd = stream_of[d];
-            if (tail[sd] == d && pos_in_order[d] > best) { best = pos_in_order[d]; s = sd; }
+            if (tail[sd] != d || pos_in_order[d] <= best) continue;
+            if (keep_chains) {            // does a later successor of d have more of the graph behind it?  Then the stream is kept for that one.
+                bool outlived = false;
+                for (int u : succ[d]) if (u != v && stream_of[u] < 0 && way[u] > way[v]) { outlived = true; break; }
+                if (outlived) continue;
+            }
+            best = pos_in_order[d]; s = sd;
         }
         if (s < 0) {
             for (int t = 0; t < nstreams && s < 0; ++t) if (tail[t] < 0) s = t;

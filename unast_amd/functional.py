@@ -512,6 +512,48 @@ def text_decode(cx, tape, m, ids, lens_q, mem, lens_k, Tk, shift=True, loss_hint
     x = text_embed(cx, tape, ids, T, a.t_pre_drop, False, 1 if shift else -1)          # SOS_IDX = 1
     x = posenc(cx, tape, x, m.pe, T)
     x = decoder_stack(cx, tape, x, lens_q, mem, lens_k, "text_m.decoder.transformer_decoder.layers.", a.num_layers, B, T, Tk, a.nhead, a.d_drop)
+    return text_decode_tail(cx, tape, m, x, loss_hint=loss_hint)
+
+
+def text_decode_pair(cx, tape, m, ids2, lens_q2, mems, lens_ks, Tks, loss_hints):
+    """TextTransformer.decode_sequence of TWO calls of one target shape (the auto-encoder's text decoder and the ASR decoder of one generator
+    phase): embeddings + positional encoding per call into one buffer, the decoder stack once over both (decoder_stack_pair), TextPostnet
+    head + loss per call.  Returns the two logits Vars."""
+    B, T = ids2[0].shape
+    a = m.args
+    N = B * T
+    E = cx.P["text_m.prenet.embed.weight"].shape[1]
+    buf = _empty(2 * N, E, device=ids2[0].device)
+    halves = [posenc(cx, tape, text_embed(cx, tape, ids2[h], T, a.t_pre_drop, False, 1), m.pe, T, out=buf[h * N:(h + 1) * N]) for h in range(2)]
+    x2 = _stack_rows(cx, tape, halves, buf)
+    y2 = decoder_stack_pair(cx, tape, x2, lens_q2, mems, lens_ks, Tks, "text_m.decoder.transformer_decoder.layers.", a.num_layers, B, T, a.nhead, a.d_drop)
+    gbuf = {}
+    xs = [Var(y2.v[h * N:(h + 1) * N]) for h in range(2)]
+    if tape is not None:
+        def join():                                   # recorded before the tails => runs after them
+            if "g" in gbuf:
+                for h in range(2):
+                    blk = gbuf["g"][h * N:(h + 1) * N]
+                    if xs[h].g is None:
+                        blk.zero_()
+                    elif xs[h].g.data_ptr() != blk.data_ptr():
+                        ops.sum2(blk, xs[h].g.contiguous())
+                acc(y2, gbuf["g"])
+        tape.record(join)
+
+    def dx_block(h):
+        def get():
+            if "g" not in gbuf:
+                gbuf["g"] = _empty(2 * N, E, like=y2.v)
+            return gbuf["g"][h * N:(h + 1) * N]
+        return get
+    return [text_decode_tail(cx, tape, m, xs[h], loss_hint=loss_hints[h], dx_out=dx_block(h)) for h in range(2)]
+
+
+def text_decode_tail(cx, tape, m, x, loss_hint=None, dx_out=None):
+    """TextPostnet (dropout + fc1, src/module.py:233-246) on decoder states x (Var [B*T, E]), with the loss in the head's launch when the
+    step announced it.  dx_out: where the backward puts d(loss)/dx (a row block of a paired call's gradient buffer)."""
+    a = m.args
     N, E = x.v.shape
     p = cx.p(a.t_post_drop)
     s = cx.stream()
@@ -548,10 +590,11 @@ def text_decode(cx, tape, m, ids, lens_q, mem, lens_k, Tk, shift=True, loss_hint
             gW = st.g("text_m.postnet.fc1.weight")
             if gW is not None:
                 ops.linear_wgrad(dl[:, :V], xd, gW, db=st.g("text_m.postnet.fc1.bias"))
-            dxd = _empty(N, E, like=xd)
+            last = dx_out() if dx_out is not None else None
+            dxd = last if (last is not None and p <= 0) else _empty(N, E, like=xd)
             ops.linear_dgrad(dl[:, :V], W, dxd)
             if p > 0:
-                dx = _empty(N, E, like=xd)
+                dx = last if last is not None else _empty(N, E, like=xd)
                 ops.leaky_dropout(x.v, dxd, dx, 1.0, drop_p=p, seed=seed, stream_id=s)
             else:
                 dx = dxd

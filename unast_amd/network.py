@@ -267,6 +267,35 @@ class TextTransformer(AutoEncoderNet):
         return run_segment(run, ddp_hook("text_dec", cx.st), cx.st.dummy, enc_outputs)
 
     @on_stream("text")
+    def decode_pair(self, tgt_a, lens_a, enc_a, masks_a, hint_a, tgt_b, lens_b, enc_b, masks_b, hint_b):
+        """Two decode_sequence calls of one target shape as a single call (see SpeechTransformer.decode_pair): the decoder stack once over
+        both, cross-attention per call on its own memory, head + loss per call.  Returns the two logits tensors."""
+        if tgt_a.shape != tgt_b.shape:
+            raise ValueError("decode_pair: the two targets must have one shape")
+        B, T = tgt_a.shape
+        Tks = (enc_a.shape[1], enc_b.shape[1])
+        lq = torch.cat([lens_i32(lens_a, tgt_a.device), lens_i32(lens_b, tgt_b.device)])
+        lens_ks = (masks_a[1], masks_b[1])
+        cx = self._ctx()
+        ids2 = (tgt_a.contiguous(), tgt_b.contiguous())
+        V = self.postnet.fc1.weight.shape[0]
+
+        def run(tape, dummy, mem_a, mem_b):
+            mems = (_mem_in(tape, mem_a, B, Tks[0]), _mem_in(tape, mem_b, B, Tks[1]))
+            res = []
+            for out in F.text_decode_pair(cx, tape, self, ids2, lq, mems, lens_ks, Tks, (hint_a, hint_b)):
+                ldl = out.v.shape[1]
+                o = Var(out.v.view(B, T, ldl)[..., :V])
+                if tape is not None:
+                    def bwd(o=o, out=out, ldl=ldl):
+                        if o.g is not None:
+                            out.g = _as_padded(o.g, B * T, ldl, V)
+                    tape.record(bwd)
+                res.append(o)
+            return res
+        return run_segment(run, ddp_hook("text_dec", cx.st), cx.st.dummy, enc_a, enc_b)
+
+    @on_stream("text")
     def decode(self, tgt, tgt_lens, tgt_pad_mask, enc_outputs, enc_mask):
         """src/network.py:446-450: one uncached generation step -- the decoder over all of `tgt` (token ids [B,T], fed as they are),
         logits [B,1,V] of its last position.  Forward only (no tape); generation proper runs on the K/V cache (infer_sequence)."""

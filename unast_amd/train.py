@@ -577,7 +577,13 @@ def train_gen_joint_step(losses, model, ae_batch, sp_batch, step, accum_steps, a
         # the auto-encoder sub-step's decoders, then the supervised sub-step's (BatchNorm of the speech post-net: first ae, then tts)
         gs = 1.0 / float(accum_steps)          # the upstream gradient of every loss of this step (train._LossSum): the fused head + loss launches apply it
         dev = t_enc_a.device
-        text_pred_a = model.text_m.decode_sequence(text_a, tl_a, t_enc_a, t_masks_a, loss_hint=(ya[0], args.t_eos_weight, gs, _loss_ws(dev))).permute(0, 2, 1)
+        th_a, th_s = (ya[0], args.t_eos_weight, gs, _loss_ws(dev)), (ys[0], args.t_eos_weight, gs, _loss_ws(dev))
+        pair_text = config.JOINT_DECODERS and text_a.shape == text_s.shape
+        if pair_text:           # the auto-encoder's text decoder and the ASR decoder as one call (memories: text / speech encoder output)
+            text_pred_a, text_pred_s = (o.permute(0, 2, 1) for o in model.text_m.decode_pair(text_a, tl_a, t_enc_a, t_masks_a, th_a,
+                                                                                             text_s, tl_s, s_enc_s, s_masks_s, th_s))
+        else:
+            text_pred_a = model.text_m.decode_sequence(text_a, tl_a, t_enc_a, t_masks_a, loss_hint=th_a).permute(0, 2, 1)
         hint_a, hint_s = (ya[1], ml_a, args.s_eos_weight, gs, _loss_ws(dev)), (ys[1], ml_s, args.s_eos_weight, gs, _loss_ws(dev))
         if config.JOINT_DECODERS and mel_a.shape == mel_s.shape:
             # the auto-encoder's speech decoder and the TTS decoder as one call: the stack once over both, cross-attention per call
@@ -586,7 +592,8 @@ def train_gen_joint_step(losses, model, ae_batch, sp_batch, step, accum_steps, a
         else:
             pre_a, post_a, stop_a, _ = model.speech_m.decode_sequence(mel_a, ml_a, s_enc_a, s_masks_a, loss_hint=hint_a)
             pre_s, post_s, stop_s, _ = model.speech_m.decode_sequence(mel_s, ml_s, t_enc_s, t_masks_s, loss_hint=hint_s)
-        text_pred_s = model.text_m.decode_sequence(text_s, tl_s, s_enc_s, s_masks_s, loss_hint=(ys[0], args.t_eos_weight, gs, _loss_ws(dev))).permute(0, 2, 1)
+        if not pair_text:
+            text_pred_s = model.text_m.decode_sequence(text_s, tl_s, s_enc_s, s_masks_s, loss_hint=th_s).permute(0, 2, 1)
         if not _JOINT_D_FIRST:
             d_ae_loss, d_sp_loss = disc_losses()
         s_ae_loss = speech_loss(ya[1], ya[2], pre_a, post_a, ml_a, stop_a, args.s_eos_weight)
