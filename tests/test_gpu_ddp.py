@@ -29,6 +29,10 @@ args = make_args(num_layers=1, ae_steps=1, sp_steps=0 if CM else 1, d_steps=1, c
 utils.set_seed(7); utils.set_deterministic(True)
 _, _, model, opt, sched = train.initialize_model(args)
 opt.param_groups[0]["lr"] = 1e-3
+if os.environ.get("TEST_PERTURB"):                     # tools/replay_noise.py: how fast does one ulp in the weights grow over the steps?
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.0 + float(os.environ["TEST_PERTURB"]))
 SHAPES = os.environ.get("TEST_RANK_SHAPES", "0") == "1"          # each rank pads to its own lengths, as ranks of a real job do
 shape = (2, 16, 40) if (rank == 0 or not SHAPES) else (3, 12, 56)
 batch = tuple(torch.from_numpy(x) for x in synth_batch(*shape, seed=rank, ragged=True))      # different data per rank
@@ -178,6 +182,9 @@ def test_two_ranks_cross_model_last_substep_overlap_equals_blocking(tmp_path):
     _same(torch.load(str(tmp_path / "ov") + ".0"), torch.load(str(tmp_path / "blk") + ".0"))
 
 
+_STEP_BOUNDS = [1e-5, 1e-4, 5e-4, 2e-3, 2e-2]          # per step, see the comment in the test below
+
+
 def test_single_rank_nccl_replayed_step_issues_the_collectives_from_cpp(tmp_path):
     """Under a process group the train step is captured with marker nodes where the gradient buckets are exchanged; the stream-replay
     executor issues unast_allreduce (RCCL through the C ABI) there.  Five replayed steps equal five eager steps of the torch.distributed path."""
@@ -185,10 +192,15 @@ def test_single_rank_nccl_replayed_step_issues_the_collectives_from_cpp(tmp_path
     _run(tmp_path, 1, 29557, TEST_BACKEND="nccl", UNAST_DDP_FORCE="1", TEST_GRAPH="1", TEST_SAVE=str(tmp_path / "g"))
     _run(tmp_path, 1, 29559, TEST_BACKEND="nccl", UNAST_DDP_FORCE="1", UNAST_NATIVE_COMM="0", TEST_STEPS="5", TEST_SAVE=str(tmp_path / "e"))
     a, b = torch.load(str(tmp_path / "g") + ".0"), torch.load(str(tmp_path / "e") + ".0")
+    # Bounds per step, not one for all five: two EAGER runs of this worker already differ by 6e-8 / 8e-6 / 4e-5 / 2e-4 / 3e-3 in the
+    # discriminator loss (atomic accumulation order; lr 1e-3 on a 2-utterance batch amplifies it ~10x per step), one ulp in the weights
+    # grows to 5e-3 by step five -- profiles/r04_replay_noise.txt, tools/replay_noise.py.  A collective issued twice, skipped or on
+    # stale gradients shows in step two already, where the bound is 1e-4.
+    bounds = _STEP_BOUNDS
     for k in a["losses"]:
         assert len(a["losses"][k]) == len(b["losses"][k]) == 5, (k, len(a["losses"][k]), len(b["losses"][k]))
-        for x, y in zip(a["losses"][k], b["losses"][k]):
-            assert abs(x - y) < 2e-3 * max(1.0, abs(y)), (k, a["losses"][k], b["losses"][k])
+        for x, y, tol in zip(a["losses"][k], b["losses"][k], bounds):
+            assert abs(x - y) < tol * max(1.0, abs(y)), (k, a["losses"][k], b["losses"][k])
 
 
 SHIM = os.path.join(ROOT, "tests", "native", "libfake_rccl.so")
@@ -202,8 +214,8 @@ def _need_shim():
 def _close(a, b, steps=5):
     for k in a["losses"]:
         assert len(a["losses"][k]) == len(b["losses"][k]) == steps, (k, len(a["losses"][k]), len(b["losses"][k]))
-        for x, y in zip(a["losses"][k], b["losses"][k]):
-            assert abs(x - y) < 2e-3 * max(1.0, abs(y)), (k, a["losses"][k], b["losses"][k])
+        for x, y, tol in zip(a["losses"][k], b["losses"][k], _STEP_BOUNDS):
+            assert abs(x - y) < tol * max(1.0, abs(y)), (k, a["losses"][k], b["losses"][k])
 
 
 @pytest.mark.parametrize("jitter", ["0", "200"])
