@@ -29,17 +29,51 @@ __device__ __forceinline__ void swap32(float v, float& lower, float& upper) {
     lower = __uint_as_float(a[0]); upper = __uint_as_float(a[1]);
 }
 
+// The recurrent dot products without LDS broadcasts (round 4, second pass).  A lane holds ONE value per group of 16 source elements (one
+// ds_read_b32: lane c of every 16-lane row has element 16 G + c), and the 16 values of a row reach every lane of it by DPP row rotations
+// folded into the multiply-add (v_fmac_f32_dpp row_ror:n, full rate).  The weight a lane multiplies rotation n with belongs to the lane
+// that rotation n reads from; that lane index comes from the same DPP operation applied to the lane id at kernel start (RotSrc), so
+// nothing here depends on which way the hardware calls "right".
+// One asm block per group: hipcc (ROCm 7.2) neither folds a v_mov_b32_dpp into the multiply-add nor schedules 16 separate asm statements
+// without an s_nop between every four.  The first multiply-add is the unrotated one and an s_nop follows it: two wait states between
+// whatever wrote `v` and the first DPP read of it (the hazard recogniser does not look inside asm).
+template <int N>
+__device__ __forceinline__ int row_ror_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x120 + N, 0xf, 0xf, true); }
+template <int N>
+struct RotSrc { static __device__ __forceinline__ void fill(int c, int (&src)[16]) { src[N] = row_ror_i<N>(c); RotSrc<N + 1>::fill(c, src); } };
+template <> struct RotSrc<0> { static __device__ __forceinline__ void fill(int c, int (&src)[16]) { src[0] = c; RotSrc<1>::fill(c, src); } };
+template <> struct RotSrc<16> { static __device__ __forceinline__ void fill(int, int (&)[16]) {} };
+__device__ __forceinline__ float row_ror8(float v) { return __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x128, 0xf, 0xf, true)); }
+
+// acc[n & 3] += w[n] * (v rotated by n) for n = 0..15: four independent chains
+__device__ __forceinline__ void dot16(const float (&w)[16], float v, float (&acc)[4]) {
+#define D(n, a, wi) "v_fmac_f32_dpp %" #a ", %4, %" #wi " row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"
+    asm("v_fmac_f32_e32 %0, %4, %5\n\ts_nop 0\n\t"
+        D(1, 1, 6) D(2, 2, 7) D(3, 3, 8) D(4, 0, 9) D(5, 1, 10) D(6, 2, 11) D(7, 3, 12) D(8, 0, 13) D(9, 1, 14) D(10, 2, 15) D(11, 3, 16)
+        D(12, 0, 17) D(13, 1, 18) D(14, 2, 19) D(15, 3, 20)
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+        : "v"(v), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]),
+          "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+#undef D
+}
+
+#define LOG2E 1.4426950408889634f
+
 // xproj [Bd,T,ndir*LG] (no bias), y [Bd,T,ndir*LH], gates [Bd,T,ndir,LG], cs [Bd,T,ndir,LH], hprev [Bd,T,ndir,LH], hfinal [Bd, ndir*LH].
 // y and hprev of the padded steps t >= len are written as zeros here (they are GEMM operands of the next layer / of the weight
 // gradients over all Bd*T rows): the caller allocates them uninitialised -- pre-zeroing them with a fill launch each was 26 MB of
 // memset per tensor and call at config 3.
 //
-// Round 4 layout: the four gates of a hidden unit live in ONE wave.  Wave w owns units [16 w, 16 w + 16); lane l = 16 q + c computes gate
-// q (i, f, g, o) of unit 16 w + c, i.e. row 64 q + 16 w + c of W_hh (64 floats in VGPRs).  After the activation three permlane swaps hand
-// every lane the other three gates of its unit, the cell update happens in place (four times redundantly), and the only thing that
-// crosses waves is h: 16 values per wave into a double-buffered LDS vector, ONE barrier per step, one LDS round trip on the step's
-// dependent chain (the round-1..3 form published the activated gates through LDS, met at the barrier, read four gates back, and then
-// paid a second write -> read hop for its wave-private copy of h: ~1 050 cycles per step, of which the two hops were about a third).
+// Layout (round 4): the four gates of a hidden unit live in ONE wave.  Wave w owns units [16 w, 16 w + 16); lane l = 16 q + c computes gate
+// q (i, f, g, o) of unit 16 w + c, i.e. row 64 q + 16 w + c of W_hh (64 floats in VGPRs, in rotation order -- dot16 above; its own wave's h
+// comes from the register, the other waves' by one ds_read_b32 each).  After the activation three permlane swaps hand every lane the other
+// three gates of its unit, the cell update happens in place (four times redundantly), and the only thing that crosses waves is h: 16 values
+// per wave into a double-buffered LDS vector, ONE barrier per step, one LDS round trip on the step's dependent chain.  The 16 multiply-adds
+// on the wave's OWN units run in front of the barrier, for the next step (under the LDS write and the wait for the slowest wave): 326 ->
+// 283 us at 64 x 800; c, y and hprev leave in one store (lane rows 0, 1, 2) instead of three: -> 278 us.
+// Measured and dropped (tools/lstm_knockout.sh): 512 threads with every dot product split over two lanes (32 multiply-adds per
+// lane, two waves per SIMD) is SLOWER, 347 against 300 us at 64 x 800 -- a SIMD issues one unpacked fp32 instruction per 4 cycles whichever
+// wave it comes from, so the split halves nothing and doubles the activation / swap / store instructions per SIMD.
 // Global latency stays off the chain: the projections of FCH steps are register-resident while the next chunk's loads are in flight.
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ xproj, const float* __restrict__ whh, const float* __restrict__ b_ih,
                                                        const float* __restrict__ b_hh, const int* __restrict__ lens, float* __restrict__ y,
@@ -47,18 +81,21 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ hfinal, int T, int ndir, size_t whh_dir_stride, size_t bias_dir_stride) {
     __shared__ __attribute__((aligned(16))) float h_lds[2][LH];
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
-    const int wave = j >> 6, lane = j & 63, q = lane >> 4;
-    const int u = 16 * wave + (lane & 15);             // hidden unit of this lane
+    const int wave = j >> 6, lane = j & 63, q = lane >> 4, c16 = lane & 15;
+    const int u = 16 * wave + c16;                     // hidden unit of this lane
     const int row = q * LH + u;                        // its gate row
     const int len = lens[b];
-    f32x2 w[LH / 2];                       // row `row` of W_hh as register pairs: the dot product below runs on v_pk_fma_f32
+    // w[jw][n] = W_hh[row][16 ((wave + jw) & 3) + src[n]]: the weights of source wave (wave + jw) & 3 in the order the rotations deliver h
+    float w[4][16];
+    int src[16];
+    RotSrc<0>::fill(c16, src);
     const float* wr = whh + dir * whh_dir_stride + (size_t)row * LH;
 #pragma unroll
-    for (int k = 0; k < LH; k += 4) {
-        float4 v = *reinterpret_cast<const float4*>(wr + k);
-        w[k / 2] = (f32x2){v.x, v.y}; w[k / 2 + 1] = (f32x2){v.z, v.w};
-    }
+    for (int jw = 0; jw < 4; ++jw)
+#pragma unroll
+        for (int n = 0; n < 16; ++n) w[jw][n] = wr[16 * ((wave + jw) & 3) + src[n]];
     const float bias = b_ih[dir * bias_dir_stride + row] + b_hh[dir * bias_dir_stride + row];
+    const int hs1 = 16 * ((wave + 1) & 3) + c16, hs2 = 16 * ((wave + 2) & 3) + c16, hs3 = 16 * ((wave + 3) & 3) + c16;
     if (j < LH) h_lds[0][j] = 0.f;
     for (int t = max(len, 0) + wave; t < T; t += 4) {                // padded steps: wave w clears every 4th one (lane = unit here)
         y[((size_t)b * T + t) * ((size_t)ndir * LH) + dir * LH + lane] = 0.f;
@@ -74,17 +111,20 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
     const float* xp = xproj + (size_t)b * T * xs + (size_t)dir * LG + row;
     const int tstep = dir ? -1 : 1;
     const int t0 = dir ? len - 1 : 0;
-    // Output pointers of the first step, advanced by one time step per iteration (the 64-bit row arithmetic per step was
-    // a fifth of the step's instructions, all of them on its dependent chain).
-    const size_t row0 = ((size_t)b * T + t0) * ndir + dir;
-    float* gp = gates + row0 * LG + row;
-    float* hp = hprev + row0 * LH + u;
-    float* cp = cs + row0 * LH + u;
-    float* yp = y + ((size_t)b * T + t0) * ((size_t)ndir * LH) + dir * LH + u;
-    const ptrdiff_t g_inc = (ptrdiff_t)tstep * ndir * LG, h_inc = (ptrdiff_t)tstep * ndir * LH, y_inc = (ptrdiff_t)tstep * ndir * LH;
-    // sigmoid(x) = 1 / (1 + exp(-x)), tanh(x) = 2 / (1 + exp(-2x)) - 1: one branch-free form with per-lane constants (lane row 2 = g)
-    const float act_m = (q == 2) ? -2.f : -1.f, act_s = (q == 2) ? 2.f : 1.f, act_o = (q == 2) ? -1.f : 0.f;
+    // The activated gates leave through a buffer descriptor over this sequence's slab: the per-lane part of the address is fixed for the
+    // launch, the time step advances in a scalar register.
     const bool writer = q == 0;                                      // one lane row per wave stores the unit's state
+    const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(gates + (size_t)b * T * ndir * LG, 0, (int)((size_t)T * ndir * LG * 4), 0x00020000);
+    const uint32_t g_vo = (uint32_t)(dir * LG + row) * 4u;
+    int g_so = t0 * ndir * LG * 4;                                   // scalar byte offset of the current time step
+    const int g_inc = tstep * ndir * LG * 4;
+    // sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(x) = 2 / (1 + 2^(-2 x log2 e)) - 1: one branch-free form with per-lane constants (lane row 2 = g)
+    const float act_m = (q == 2) ? -2.f * LOG2E : -LOG2E, act_s = (q == 2) ? 2.f : 1.f, act_o = (q == 2) ? -1.f : 0.f;
+    // The unit's state leaves in ONE store per step: lane row 0 writes c_t, row 1 y_t = h_t, row 2 hprev_t = h_{t-1} (every lane of the unit
+    // has all three), row 3 nothing -- three 16-lane stores cost three issue slots of the in-order wave.
+    const size_t st_row0 = ((size_t)b * T + t0) * ndir + dir;
+    float* st_p = q == 0 ? cs + st_row0 * LH + u : q == 1 ? y + ((size_t)b * T + t0) * ((size_t)ndir * LH) + dir * LH + u : hprev + st_row0 * LH + u;
+    const ptrdiff_t st_inc = (ptrdiff_t)tstep * ndir * LH;
     float xc[FCH], xn[FCH];
     auto load_chunk = [&](int s0, float (&x)[FCH]) {
 #pragma unroll
@@ -94,37 +134,60 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
         }
     };
     load_chunk(0, xn);
+    float accn[4] = {0.f, 0.f, 0.f, 0.f};                            // this wave's 16 units' share of the NEXT step's dot product (h = 0 before the first)
     for (int s0 = 0; s0 < len; s0 += FCH) {
 #pragma unroll
-        for (int i = 0; i < FCH; ++i) xc[i] = xn[i];                // the only wait for global loads: once per chunk
+        for (int i = 0; i < FCH; ++i) xc[i] = xn[i] + bias;          // the only wait for global loads: once per chunk
         if (s0 + FCH < len) load_chunk(s0 + FCH, xn);
 #pragma unroll
         for (int i = 0; i < FCH; ++i) {
             if (s0 + i < len) {                                      // (uniform; a guard, not a break, so that the chunk unrolls and xc[i] is a register)
                 const float* hl = h_lds[i & 1];                      // (FCH is even: the step's parity is i & 1)
-                f32x2 a0 = {xc[i] + bias, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};     // four independent chains of 8 packed FMAs
-#pragma unroll
-                for (int k = 0; k < LH; k += 8) {
-                    const float4 hv0 = *reinterpret_cast<const float4*>(&hl[k]);
-                    const float4 hv1 = *reinterpret_cast<const float4*>(&hl[k + 4]);
-                    a0 = __builtin_elementwise_fma(w[k / 2], (f32x2){hv0.x, hv0.y}, a0);
-                    a1 = __builtin_elementwise_fma(w[k / 2 + 1], (f32x2){hv0.z, hv0.w}, a1);
-                    a2 = __builtin_elementwise_fma(w[k / 2 + 2], (f32x2){hv1.x, hv1.y}, a2);
-                    a3 = __builtin_elementwise_fma(w[k / 2 + 3], (f32x2){hv1.z, hv1.w}, a3);
-                }
-                const float pre = ((a0[0] + a0[1]) + (a1[0] + a1[1])) + ((a2[0] + a2[1]) + (a3[0] + a3[1]));
-                const float act = __builtin_fmaf(__builtin_amdgcn_rcpf(1.f + __expf(act_m * pre)), act_s, act_o);
-                *gp = act;
+                // (LKO_*: timing-only knock-out builds, tools/lstm_knockout.sh; never defined in the shipped library)
+#ifdef LKO_LDS
+                const float h1 = h, h2 = h, h3 = h;
+#else
+                const float h1 = hl[hs1], h2 = hl[hs2], h3 = hl[hs3];    // the other waves' units, one value per lane; this wave's are in `h`
+#endif
+                float acc[4] = {accn[0] + xc[i], accn[1], accn[2], accn[3]};
+#ifdef LKO_DOT
+                acc[1] = h * w[0][0]; acc[2] = h1 * w[1][0]; acc[3] = h2 * w[2][0] + h3 * w[3][0];
+#else
+                dot16(w[1], h1, acc);
+                dot16(w[2], h2, acc);
+                dot16(w[3], h3, acc);
+#endif
+                const float pre = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#ifdef LKO_ACT
+                const float act = __builtin_fmaf(pre, act_s, act_o);
+#else
+                const float act = __builtin_fmaf(__builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(act_m * pre)), act_s, act_o);
+#endif
+#ifndef LKO_STORES
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(act), g_rs, g_vo, g_so, 0);
+#endif
+                const float h_before = h;
                 float e16, o16, ig, gg, fg, og;
                 swap16(act, e16, o16);                               // rows (0, 1): (i, f); rows (2, 3): (g, o)
                 swap32(e16, ig, gg);
                 swap32(o16, fg, og);
-                if (writer) *hp = h;
                 c = fg * c + ig * gg;
-                h = og * tanhf_(c);
-                if (writer) { *cp = c; *yp = h; h_lds[(i + 1) & 1][u] = h; }
-                gp += g_inc; hp += h_inc; cp += h_inc; yp += y_inc;
+#ifdef LKO_ACT
+                h = og * c;
+#else
+                h = og * __builtin_fmaf(__builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f((-2.f * LOG2E) * c)), 2.f, -1.f);
+#endif
+#ifndef LKO_STORES
+                if (q < 3) *st_p = q == 0 ? c : q == 1 ? h : h_before;
+                st_p += st_inc;
+#endif
+                if (writer) h_lds[(i + 1) & 1][u] = h;
+                accn[0] = accn[1] = accn[2] = accn[3] = 0.f;
+                dot16(w[0], h, accn);                                // the next step's share of this wave's own units: before the barrier
+                g_so += g_inc;
+#ifndef LKO_BARRIER
                 __syncthreads();
+#endif
             }
         }
     }
@@ -133,24 +196,33 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
 
 // Backward through time.  dy [Bd,T,ndir*LH] (may be null), dhfinal [Bd,ndir*LH] (may be null),
 // dgates [Bd,T,ndir,LG]: receives d(pre-activation gates) for the valid steps and zeros for the padded ones (t >= len).
-// Same ownership as the forward (round 4): wave w owns units [16 w, 16 w + 16), lane l = 16 q + c.  Every lane forms the cell's gradients
-// of ITS unit from registers (saved gates / cell states / dy of BCH steps are register-resident while the next chunk's loads are in
-// flight), keeps the one of gate q, and publishes it in a double-buffered LDS vector of the 256 gate gradients -- ONE barrier --; then
-// lane (q, c) multiplies the 64 gradients of gate type q by column 16 w + c of that gate's W_hh block and two permlane swaps sum the four
-// gate types: dh of the previous step, in every lane of the unit, without a second trip through LDS (the earlier form split the gate
-// rows over the waves, wrote its partial sums to LDS and summed them after the barrier: two hops per step).
+// 256 threads: wave w owns units [16 w, 16 w + 16), lane l = 16 q + c is gate q (i, f, g, o) of unit 16 w + c.  (The forward's split of a
+// dot product over two lanes does not carry over: here a 16-lane row must hold ONE gate type -- the rotations hand every lane of a row the
+// same 16 gate gradients -- and 16 different units, which leaves four rows = four gate types per unit in a wave and nothing to split
+// without a second trip through LDS.)  Every lane forms the cell's gradients of ITS unit from registers (saved gates / cell states / dy of
+// BCH steps are register-resident while the next chunk's loads are in flight; everything that does not depend on dh / dc is computed
+// ahead of the step), keeps the one of gate q, and publishes it in a double-buffered LDS vector of the 256 gate gradients -- ONE barrier --;
+// then lane (q, c) multiplies the 64 gradients of gate type q by column 16 w + c of that gate's W_hh block (its own wave's 16 from the
+// register, the other waves' by one ds_read_b32 each, all by row rotations) and two permlane swaps sum the four gate types: dh of the
+// previous step, in every lane of the unit.
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dhfinal, const float* __restrict__ whh,
                                                        const float* __restrict__ gates, const float* __restrict__ cs, const int* __restrict__ lens,
                                                        float* __restrict__ dgates, int T, int ndir, size_t whh_dir_stride) {
     __shared__ __attribute__((aligned(16))) float dg_lds[2][LG];
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
     const int len = lens[b];
-    const int wave = j >> 6, lane = j & 63, q = lane >> 4;
-    const int k = 16 * wave + (lane & 15);          // this lane's hidden unit
-    f32x2 wt[LH / 2];                   // wt[i] = {W_hh[64 q + 2i][k], W_hh[64 q + 2i + 1][k]}: register pairs for v_pk_fma_f32
+    const int wave = j >> 6, lane = j & 63, q = lane >> 4, c16 = lane & 15;
+    const int k = 16 * wave + c16;                  // this lane's hidden unit
+    // wt[jw][n] = W_hh[64 q + 16 ((wave + jw) & 3) + src[n]][k]: column k of gate block q, in the order the rotations deliver the gate gradients
+    float wt[4][16];
+    int src[16];
+    RotSrc<0>::fill(c16, src);
     const float* wr = whh + dir * whh_dir_stride + (size_t)(q * LH) * LH + k;
 #pragma unroll
-    for (int i = 0; i < LH; i += 2) wt[i / 2] = (f32x2){wr[(size_t)i * LH], wr[(size_t)(i + 1) * LH]};
+    for (int jw = 0; jw < 4; ++jw)
+#pragma unroll
+        for (int n = 0; n < 16; ++n) wt[jw][n] = wr[(size_t)(16 * ((wave + jw) & 3) + src[n]) * LH];
+    const int ds1 = q * LH + 16 * ((wave + 1) & 3) + c16, ds2 = q * LH + 16 * ((wave + 2) & 3) + c16, ds3 = q * LH + 16 * ((wave + 3) & 3) + c16;
     float dh = 0.f, dc = 0.f;
     if (dhfinal) dh = dhfinal[(size_t)b * (ndir * LH) + dir * LH + k];
     const int tstep = dir ? 1 : -1;                         // reverse of the forward processing order
@@ -172,48 +244,48 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     };
     for (int t = max(len, 0); t < T; ++t) dgates[(((size_t)b * T + t) * ndir + dir) * LG + j] = 0.f;       // padded steps: 1 KB per step
     if (len <= 0) return;                                   // (uniform)
-    float* dgr = dgates + (((size_t)b * T + t0) * ndir + dir) * LG + q * LH + k;        // advanced by one time step per iteration
-    const ptrdiff_t dg_inc = (ptrdiff_t)tstep * ndir * LG;
+    const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(dgates + (size_t)b * T * ndir * LG, 0, (int)((size_t)T * ndir * LG * 4), 0x00020000);
+    const uint32_t d_vo = (uint32_t)(dir * LG + q * LH + k) * 4u;
+    int d_so = t0 * ndir * LG * 4;                          // scalar byte offset of the current time step
+    const int d_inc = tstep * ndir * LG * 4;
+    const bool is_o = q == 3;
     load_chunk(0, vn);
     for (int r0 = 0; r0 < len; r0 += BCH) {
+        // Per step, off the dependent chain: with dht = dh + dy and dct = dc + dht B, the gate gradient of this lane is X Y where
+        // X = dht (gate o) or dct (gates i, f, g) and Y = A (o), Ci, Cf or Cg; dc = dct fg.
+        float cy[BCH], cB[BCH], cf[BCH], cd[BCH];
 #pragma unroll
-        for (int i = 0; i < BCH; ++i)
-#pragma unroll
-            for (int qq = 0; qq < 7; ++qq) vc[i][qq] = vn[i][qq];
+        for (int i = 0; i < BCH; ++i) {
+            const float ig = vn[i][0], fg = vn[i][1], gg = vn[i][2], og = vn[i][3];
+            const float cprev = (r0 + i >= len - 1) ? 0.f : vn[i][5];          // (steps beyond the sequence are never used)
+            const float tc = tanhf_(vn[i][4]);
+            cB[i] = og * (1.f - tc * tc);
+            cf[i] = fg;
+            cd[i] = vn[i][6];
+            cy[i] = q == 0 ? gg * ig * (1.f - ig) : q == 1 ? cprev * fg * (1.f - fg) : q == 2 ? ig * (1.f - gg * gg) : tc * og * (1.f - og);
+        }
         if (r0 + BCH < len) load_chunk(r0 + BCH, vn);
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             const int r = r0 + i;
             if (r < len) {                                  // (uniform; a guard, not a break, so that the chunk unrolls)
-            const float ig = vc[i][0], fg = vc[i][1], gg = vc[i][2], og = vc[i][3], ct = vc[i][4];
-            const float cprev = (r == len - 1) ? 0.f : vc[i][5];
-            const float dht = dh + vc[i][6];
-            const float tc = tanhf_(ct);
-            const float d_o = dht * tc * og * (1.f - og);
-            const float dct = dc + dht * og * (1.f - tc * tc);
-            const float d_i = dct * gg * ig * (1.f - ig);
-            const float d_f = dct * cprev * fg * (1.f - fg);
-            const float d_g = dct * ig * (1.f - gg * gg);
-            dc = dct * fg;
-            const float mine = q == 0 ? d_i : q == 1 ? d_f : q == 2 ? d_g : d_o;
+            const float dht = dh + cd[i];
+            const float dct = __builtin_fmaf(dht, cB[i], dc);
+            dc = dct * cf[i];
+            const float mine = (is_o ? dht : dct) * cy[i];
             float* dgw = dg_lds[i & 1];                     // (BCH is even: the step's parity is i & 1)
             dgw[q * LH + k] = mine;
-            *dgr = mine;
-            dgr += dg_inc;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine), d_rs, d_vo, d_so, 0);
+            d_so += d_inc;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            dot16(wt[0], mine, acc);                        // this wave's own 16 gradients: in front of the barrier, under the LDS write
             __syncthreads();
-            f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};      // four independent chains of 8 packed FMAs
-#pragma unroll
-            for (int ii = 0; ii < LH; ii += 8) {
-                const float4 dv0 = *reinterpret_cast<const float4*>(&dgw[q * LH + ii]);
-                const float4 dv1 = *reinterpret_cast<const float4*>(&dgw[q * LH + ii + 4]);
-                a0 = __builtin_elementwise_fma(wt[ii / 2], (f32x2){dv0.x, dv0.y}, a0);
-                a1 = __builtin_elementwise_fma(wt[ii / 2 + 1], (f32x2){dv0.z, dv0.w}, a1);
-                a2 = __builtin_elementwise_fma(wt[ii / 2 + 2], (f32x2){dv1.x, dv1.y}, a2);
-                a3 = __builtin_elementwise_fma(wt[ii / 2 + 3], (f32x2){dv1.z, dv1.w}, a3);
-            }
-            const float part = ((a0[0] + a0[1]) + (a1[0] + a1[1])) + ((a2[0] + a2[1]) + (a3[0] + a3[1]));
+            const float d1 = dgw[ds1], d2 = dgw[ds2], d3 = dgw[ds3];     // gate type q of the other waves' units
+            dot16(wt[1], d1, acc);
+            dot16(wt[2], d2, acc);
+            dot16(wt[3], d3, acc);
             float e16, o16, lo, up;
-            swap16(part, e16, o16);
+            swap16((acc[0] + acc[1]) + (acc[2] + acc[3]), e16, o16);
             swap32(e16 + o16, lo, up);
             dh = lo + up;                                   // (i + f) + (g + o): the same sum in every lane of the unit
             }
