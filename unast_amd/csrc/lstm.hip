@@ -45,16 +45,29 @@ template <> struct RotSrc<0> { static __device__ __forceinline__ void fill(int c
 template <> struct RotSrc<16> { static __device__ __forceinline__ void fill(int, int (&)[16]) {} };
 __device__ __forceinline__ float row_ror8(float v) { return __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x128, 0xf, 0xf, true)); }
 
-// acc[n & 3] += w[n] * (v rotated by n) for n = 0..15: four independent chains
+// acc[n & 3] += w[n] * (v rotated by n) for n = 0..15: four independent chains.  FIRST: the chains START here (acc = the first four products:
+// no zero-initialised accumulators -- every instruction of an in-order wave costs an issue slot of 4 cycles, a v_mov as much as a
+// multiply-add).  VALU_SRC: `v` was written by a vector instruction (not an LDS read): the unrotated product first and an s_nop give the two
+// wait states a DPP read of it needs.
+template <bool FIRST, bool VALU_SRC>
 __device__ __forceinline__ void dot16(const float (&w)[16], float v, float (&acc)[4]) {
 #define D(n, a, wi) "v_fmac_f32_dpp %" #a ", %4, %" #wi " row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"
-    asm("v_fmac_f32_e32 %0, %4, %5\n\ts_nop 0\n\t"
-        D(1, 1, 6) D(2, 2, 7) D(3, 3, 8) D(4, 0, 9) D(5, 1, 10) D(6, 2, 11) D(7, 3, 12) D(8, 0, 13) D(9, 1, 14) D(10, 2, 15) D(11, 3, 16)
-        D(12, 0, 17) D(13, 1, 18) D(14, 2, 19) D(15, 3, 20)
-        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
-        : "v"(v), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]),
-          "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+#define M(n, a, wi) "v_mul_f32_dpp %" #a ", %4, %" #wi " row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"
+#define TAIL D(4, 0, 9) D(5, 1, 10) D(6, 2, 11) D(7, 3, 12) D(8, 0, 13) D(9, 1, 14) D(10, 2, 15) D(11, 3, 16) D(12, 0, 17) D(13, 1, 18) D(14, 2, 19) D(15, 3, 20)
+#define OPS : "v"(v), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), \
+              "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15])
+    if constexpr (FIRST && VALU_SRC)
+        asm("v_mul_f32_e32 %0, %4, %5\n\ts_nop 0\n\t" M(1, 1, 6) M(2, 2, 7) M(3, 3, 8) TAIL : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3]) OPS);
+    else if constexpr (FIRST)
+        asm("v_mul_f32_e32 %0, %4, %5\n\t" M(1, 1, 6) M(2, 2, 7) M(3, 3, 8) TAIL : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3]) OPS);
+    else if constexpr (VALU_SRC)
+        asm("v_fmac_f32_e32 %0, %4, %5\n\ts_nop 0\n\t" D(1, 1, 6) D(2, 2, 7) D(3, 3, 8) TAIL : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) OPS);
+    else
+        asm("v_fmac_f32_e32 %0, %4, %5\n\t" D(1, 1, 6) D(2, 2, 7) D(3, 3, 8) TAIL : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) OPS);
 #undef D
+#undef M
+#undef TAIL
+#undef OPS
 }
 
 #define LOG2E 1.4426950408889634f
@@ -153,9 +166,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
 #ifdef LKO_DOT
                 acc[1] = h * w[0][0]; acc[2] = h1 * w[1][0]; acc[3] = h2 * w[2][0] + h3 * w[3][0];
 #else
-                dot16(w[1], h1, acc);
-                dot16(w[2], h2, acc);
-                dot16(w[3], h3, acc);
+                dot16<false, false>(w[1], h1, acc);
+                dot16<false, false>(w[2], h2, acc);
+                dot16<false, false>(w[3], h3, acc);
 #endif
                 const float pre = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #ifdef LKO_ACT
@@ -182,8 +195,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
                 st_p += st_inc;
 #endif
                 if (writer) h_lds[(i + 1) & 1][u] = h;
-                accn[0] = accn[1] = accn[2] = accn[3] = 0.f;
-                dot16(w[0], h, accn);                                // the next step's share of this wave's own units: before the barrier
+                dot16<true, true>(w[0], h, accn);                                // the next step's share of this wave's own units: before the barrier
                 g_so += g_inc;
 #ifndef LKO_BARRIER
                 __syncthreads();
@@ -228,19 +240,29 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     const int tstep = dir ? 1 : -1;                         // reverse of the forward processing order
     const int t0 = dir ? 0 : len - 1;
     // r = 0..len-1 counts backward steps; forward step index = len-1-r; time t = t0 + r*tstep
-    float vc[BCH][7], vn[BCH][7];
-    auto load_chunk = [&](int r0, float (&v)[BCH][7]) {
+    // Saved state through buffer descriptors over this sequence's slabs: the per-lane part of every address is fixed for the launch, the
+    // time step is a scalar offset -- the 64-bit address arithmetic of 7 loads was a quarter of the step's vector instructions, and an
+    // in-order wave pays 4 cycles for each.  dy = NULL becomes a descriptor of zero records: its loads return 0.
+    const __amdgpu_buffer_rsrc_t gl_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gates) + (size_t)b * T * ndir * LG, 0, (int)((size_t)T * ndir * LG * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t cl_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cs) + (size_t)b * T * ndir * LH, 0, (int)((size_t)T * ndir * LH * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yl_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy ? dy : cs) + (size_t)b * T * ndir * LH, 0, dy ? (int)((size_t)T * ndir * LH * 4) : 0, 0x00020000);
+    const int vo_g = (dir * LG + k) * 4, vo_c = (dir * LH + k) * 4;
+    auto ldf = [](const __amdgpu_buffer_rsrc_t& rs, int vo, int so) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0)); };
+    float vn[BCH][6], cnext;                                // gates i f g o, c_t, dy_t of BCH steps; c of the step after them
+    // The steps beyond the sequence are not clamped to its last one: their loads leave the slab at its end (the range check returns 0), stop
+    // at its first row, or read padded rows of it, and nothing computed from them is used.  Offsets advance by scalar adds.
+    const int g_incb = tstep * ndir * LG * 4, c_incb = tstep * ndir * LH * 4;
+    auto load_chunk = [&](int r0) {
+        int so_g = (t0 + r0 * tstep) * ndir * LG * 4, so_c = (t0 + r0 * tstep) * ndir * LH * 4;
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
-            const int r = min(r0 + i, len - 1);
-            const int t = t0 + r * tstep;
-            const size_t rw = ((size_t)b * T + t) * ndir + dir;
-            v[i][0] = gates[rw * LG + k]; v[i][1] = gates[rw * LG + LH + k]; v[i][2] = gates[rw * LG + 2 * LH + k]; v[i][3] = gates[rw * LG + 3 * LH + k];
-            v[i][4] = cs[rw * LH + k];
-            const int rp = min(r + 1, len - 1);             // previous forward step (clamped; masked below for the first step)
-            v[i][5] = cs[(((size_t)b * T + (t0 + rp * tstep)) * ndir + dir) * LH + k];
-            v[i][6] = dy ? dy[((size_t)b * T + t) * (ndir * LH) + dir * LH + k] : 0.f;
+            const int sg = max(so_g, 0), sc = max(so_c, 0);        // (the forward direction walks down past t = 0: no negative offsets)
+            vn[i][0] = ldf(gl_rs, vo_g, sg); vn[i][1] = ldf(gl_rs, vo_g + LH * 4, sg); vn[i][2] = ldf(gl_rs, vo_g + 2 * LH * 4, sg); vn[i][3] = ldf(gl_rs, vo_g + 3 * LH * 4, sg);
+            vn[i][4] = ldf(cl_rs, vo_c, sc);
+            vn[i][5] = ldf(yl_rs, vo_c, sc);
+            so_g += g_incb; so_c += c_incb;
         }
+        cnext = ldf(cl_rs, vo_c, max(so_c, 0));
     };
     for (int t = max(len, 0); t < T; ++t) dgates[(((size_t)b * T + t) * ndir + dir) * LG + j] = 0.f;       // padded steps: 1 KB per step
     if (len <= 0) return;                                   // (uniform)
@@ -248,23 +270,29 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     const uint32_t d_vo = (uint32_t)(dir * LG + q * LH + k) * 4u;
     int d_so = t0 * ndir * LG * 4;                          // scalar byte offset of the current time step
     const int d_inc = tstep * ndir * LG * 4;
-    const bool is_o = q == 3;
-    load_chunk(0, vn);
+    const bool q0 = q == 0, q1 = q == 1, q2 = q == 2, is_o = q == 3;
+    load_chunk(0);
     for (int r0 = 0; r0 < len; r0 += BCH) {
         // Per step, off the dependent chain: with dht = dh + dy and dct = dc + dht B, the gate gradient of this lane is X Y where
-        // X = dht (gate o) or dct (gates i, f, g) and Y = A (o), Ci, Cf or Cg; dc = dct fg.
+        // X = dht (gate o) or dct (gates i, f, g) and Y = tc og (1 - og) (o), gg ig (1 - ig) (i), cprev fg (1 - fg) (f) or ig (1 - gg gg) (g):
+        // Y = m1 m2 (1 - m2), or m1 (1 - m2 m2) for g, with the operands picked per lane row; dc = dct fg.
         float cy[BCH], cB[BCH], cf[BCH], cd[BCH];
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             const float ig = vn[i][0], fg = vn[i][1], gg = vn[i][2], og = vn[i][3];
-            const float cprev = (r0 + i >= len - 1) ? 0.f : vn[i][5];          // (steps beyond the sequence are never used)
+            const float cafter = i + 1 < BCH ? vn[i + 1][4] : cnext;           // c of the previous FORWARD step = the next backward step's
+            const float cprev = (r0 + i >= len - 1) ? 0.f : cafter;           // (scalar condition; steps beyond the sequence are never used)
             const float tc = tanhf_(vn[i][4]);
             cB[i] = og * (1.f - tc * tc);
             cf[i] = fg;
-            cd[i] = vn[i][6];
-            cy[i] = q == 0 ? gg * ig * (1.f - ig) : q == 1 ? cprev * fg * (1.f - fg) : q == 2 ? ig * (1.f - gg * gg) : tc * og * (1.f - og);
+            cd[i] = vn[i][5];
+            const float m1 = q0 ? gg : q1 ? cprev : q2 ? ig : tc;
+            const float m2 = q0 ? ig : q1 ? fg : q2 ? gg : og;
+            const float ya = m1 * m2, yb = 1.f - m2;                          // m1 m2 (1 - m2)
+            const float yc = 1.f - m2 * m2;                                   // m1 (1 - m2 m2)
+            cy[i] = q2 ? m1 * yc : ya * yb;
         }
-        if (r0 + BCH < len) load_chunk(r0 + BCH, vn);
+        if (r0 + BCH < len) load_chunk(r0 + BCH);
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             const int r = r0 + i;
@@ -277,13 +305,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
             dgw[q * LH + k] = mine;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine), d_rs, d_vo, d_so, 0);
             d_so += d_inc;
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            dot16(wt[0], mine, acc);                        // this wave's own 16 gradients: in front of the barrier, under the LDS write
+            float acc[4];
+            dot16<true, true>(wt[0], mine, acc);            // this wave's own 16 gradients: in front of the barrier, under the LDS write
             __syncthreads();
             const float d1 = dgw[ds1], d2 = dgw[ds2], d3 = dgw[ds3];     // gate type q of the other waves' units
-            dot16(wt[1], d1, acc);
-            dot16(wt[2], d2, acc);
-            dot16(wt[3], d3, acc);
+            dot16<false, false>(wt[1], d1, acc);
+            dot16<false, false>(wt[2], d2, acc);
+            dot16<false, false>(wt[3], d3, acc);
             float e16, o16, lo, up;
             swap16((acc[0] + acc[1]) + (acc[2] + acc[3]), e16, o16);
             swap32(e16 + o16, lo, up);
