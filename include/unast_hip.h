@@ -363,6 +363,17 @@ int unast_graph_plan_set_comm(int64_t plan, int64_t comm);
 /* The element counts of the plan's gradient exchanges in the order the replay issues them (up to n written to out; returns how many the
  * plan holds).  Collectives of one communicator pair up across ranks by issue order: tests compare this list with the eager step's. */
 int unast_graph_plan_allreduce_counts(int64_t plan, long long* out, int n);
+/* Keeping the program's own stream structure in the replay.  A hipGraph_t does not record which stream a node was captured on; the
+ * capture can: unast_capture_note(stream), called right after a launch on `stream` while a capture is open, remembers the node that
+ * launch created (hipStreamGetCaptureInfo_v2: the stream's dependency set is then exactly that node) as belonging to `stream`;
+ * unast_capture_reset() forgets everything (call when a capture begins).  unast_graph_plan_create then puts every noted node on a plan
+ * stream of its own capture stream when UNAST_REPLAY_LABELS=1 (as many plan streams as capture streams were seen, each with its capture
+ * stream's priority): the replay then overlaps exactly what the eager step overlaps (the side streams of unast_amd/engine.py over
+ * /root/reference/src/train.py:602-655's sub-steps).  Off by default -- it measured slower than the DAG layout.
+ * plan_streams: how many streams the plan uses. */
+int unast_capture_reset(void);
+int unast_capture_note(hipStream_t stream);
+int unast_graph_plan_streams(int64_t plan);
 
 /* Data-parallel gradient exchange over RCCL / xGMI (csrc/comm.cpp).  New with respect to the reference, which is single-device
  * (src/utils.py:101-106); the order it has to keep -- generator update before the discriminator phase -- is src/train.py:628-637.

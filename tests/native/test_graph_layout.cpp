@@ -114,6 +114,33 @@ int main() {
           std::vector<std::vector<int>> dp(n); for (int i = 0; i < n; ++i) for (int x : d[i]) dp[perm[i]].push_back(perm[x]);
           run_case("random", n, dp, s);
       } }
+    // labels (the streams the nodes were captured on): every labelled node lands on its stream, unlabelled ones join a labelled neighbour,
+    // and the layout is still a correct schedule under the adversarial simulator
+    { std::mt19937 rng(99);
+      for (int rep = 0; rep < 200; ++rep) {
+          const int n = 1 + (int)(rng() % 300), s = 1 + (int)(rng() % 6); std::vector<std::vector<int>> d(n);
+          for (int i = 1; i < n; ++i) { const int k = (int)(rng() % 3); for (int j = 0; j < k; ++j) d[i].push_back((int)(rng() % i)); }
+          std::vector<int> label(n);
+          for (int i = 0; i < n; ++i) label[i] = rng() % 5 == 0 ? -1 : (int)(rng() % s);
+          Layout lay; std::string err, why;
+          const bool ok = plan_layout(n, d, s, lay, err, true, &label);
+          CHECK(ok, "labels: plan_layout failed: %s", err.c_str());
+          if (!ok) continue;
+          CHECK(simulate(n, d, s, lay, why), "labels (%d streams): %s", s, why.c_str());
+          std::vector<char> issued(lay.event_node.size(), 0);
+          for (const LayoutOp& op : lay.ops) {
+              if (op.kind == L_NODE && label[op.id] >= 0) CHECK(op.stream == label[op.id], "labels: node %d on stream %d, captured on %d", op.id, op.stream, label[op.id]);
+              if (op.kind == L_RECORD) issued[op.id] = 1;
+              if (op.kind == L_WAIT) CHECK(issued[op.id], "labels: wait on event %d issued before its record", op.id);
+          }
+      }
+      // two captured streams that hand over twice: exactly the two waits the program made, whatever the stream count says
+      std::vector<std::vector<int>> d = {{}, {0}, {1}, {0}, {3, 2}, {4}, {2}, {6, 5}};
+      std::vector<int> label = {0, 0, 0, 1, 1, 1, 0, 0};
+      Layout lay; std::string err; CHECK(plan_layout(8, d, 2, lay, err, true, &label), "labels/two-streams: %s", err.c_str());
+      CHECK(lay.cross_edges == 3, "labels/two-streams: %d cross-stream edges, expected 3", lay.cross_edges);
+      std::vector<int> bad = {0, 0, 5, 1, 1, 1, 0, 0};
+      CHECK(!plan_layout(8, d, 2, lay, err, true, &bad), "label beyond the stream count accepted"); }
     // rejected inputs
     { Layout lay; std::string err;
       std::vector<std::vector<int>> cyc = {{2}, {0}, {1}}; CHECK(!plan_layout(3, cyc, 2, lay, err) && err.find("cycle") != std::string::npos, "cycle not detected");

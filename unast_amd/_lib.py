@@ -82,6 +82,11 @@ def ctypes_lib():
     return L
 
 
+CAPTURE_NOTE = None        # while a HIP-graph capture is open: a callable that tells the library which stream the last launch went to (engine.capture_begins)
+
+
 def check(status, what=""):
     if status != 0:
         raise UnastHipError("%s failed (%d): %s" % (what or "unast call", status, lib().unast_last_error().decode()))
+    if CAPTURE_NOTE is not None:
+        CAPTURE_NOTE()

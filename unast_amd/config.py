@@ -45,6 +45,11 @@ LN_FINALIZE_OFFLOAD = os.environ.get("UNAST_LN_FINALIZE_INLINE", "0") != "1"
 # Which logical streams share a real HIP stream ("a:x,b:x" puts a and b on the stream named x).  Experiment switch.
 STREAM_GROUPS = dict(kv.split(":") for kv in os.environ.get("UNAST_STREAM_GROUPS", "").split(",") if ":" in kv)
 
+# HIP stream priority per logical stream ("speech:-1,text:0"; lower = more urgent, as in torch.cuda.Stream(priority=)): the step's critical
+# chain is the speech side; what runs beside it on the other streams takes CUs from its kernels.  The stream replay creates its streams
+# with the priorities of the streams the nodes were captured on (csrc/graph_exec.cpp).
+STREAM_PRIORITY = {k: int(v) for k, v in (kv.split(":") for kv in os.environ.get("UNAST_STREAM_PRIO", "").split(",") if ":" in kv)}
+
 # Weight gradients of one backward closure (an attention sub-layer's out-proj + in-proj, an FFN's two linears, ...) go out as
 # ONE grouped launch (csrc/gemm.hip gemm_group_kernel) instead of one split-K launch + one reduction each; 0 = one by one.
 WGRAD_GROUP = os.environ.get("UNAST_WGRAD_GROUP", "1") != "0"

@@ -18,7 +18,9 @@
 #include <string.h>
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "common.h"
 #include "graph_layout.h"
@@ -55,6 +57,30 @@ struct Plan {
 extern "C" const void* unast_allreduce_marker_func(void);       // comm.cpp
 extern "C" int unast_graph_plan_destroy(int64_t handle);
 
+// Which stream was a node captured on?  The graph does not say; the capture does: right after a launch the capturing stream's dependency
+// set (hipStreamGetCaptureInfo_v2) is exactly the node that launch created.  The Python side calls unast_capture_note(stream) after every
+// call of this library while a capture is open (unast_amd/_lib.py check()), unast_capture_reset() when one begins.
+static std::mutex g_label_mutex;
+static std::unordered_map<hipGraphNode_t, hipStream_t> g_labels;
+
+extern "C" int unast_capture_reset(void) {
+    std::lock_guard<std::mutex> lock(g_label_mutex);
+    g_labels.clear();
+    return UNAST_OK;
+}
+
+extern "C" int unast_capture_note(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipGraph_t g = nullptr;
+    const hipGraphNode_t* dep = nullptr;
+    size_t nd = 0;
+    if (hipStreamGetCaptureInfo_v2(stream, &st, &id, &g, &dep, &nd) != hipSuccess || st != hipStreamCaptureStatusActive) return UNAST_OK;    // not capturing: nothing to note
+    std::lock_guard<std::mutex> lock(g_label_mutex);
+    for (size_t i = 0; i < nd; ++i) g_labels.emplace(dep[i], stream);       // (a node keeps the stream that noted it first: the one that launched it)
+    return UNAST_OK;
+}
+
 extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
     hipGraph_t graph = (hipGraph_t)graph_handle;
     if (!graph || nstreams < 1 || nstreams > 16) { unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: bad arguments"); return 0; }
@@ -80,10 +106,35 @@ extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
     }
     // ---- lay the DAG out on streams (graph_layout.h: pure host logic, unit-tested on the CPU under AddressSanitizer) -----------------
     unast_layout::Layout lay;
+    std::vector<int> prio;
     {
         std::string err;
         static const bool keep_chains = [] { const char* e = getenv("UNAST_REPLAY_KEEP_CHAINS"); return !(e && e[0] == '0'); }();
-        if (!unast_layout::plan_layout((int)n, deps, nstreams, lay, err, keep_chains)) { unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: %s", err.c_str()); return 0; }
+        // Off by default: with the eager step's exact stream structure (5 streams, 96 hand-offs) the replayed step measured 29.7 ms against
+        // 28.5 ms from the DAG layout below and 27.3 ms eager (tools/ab_labels.sh): what separates replay from eager is not the
+        // layout but the capture itself, which has to route side-stream hand-offs through its origin stream (engine._ViaOrigin).
+        static const bool use_labels = [] { const char* e = getenv("UNAST_REPLAY_LABELS"); return e && e[0] == '1'; }();
+        std::vector<int> label;
+        if (use_labels) {                                            // the streams the nodes were captured on, numbered by first appearance
+            std::lock_guard<std::mutex> lock(g_label_mutex);
+            std::map<hipStream_t, int> number;
+            size_t known = 0;
+            label.assign(n, -1);
+            for (size_t i = 0; i < n; ++i) {
+                auto it = g_labels.find(nodes[i]);
+                if (it == g_labels.end()) continue;
+                auto ins = number.emplace(it->second, (int)number.size());
+                label[i] = ins.first->second;
+                ++known;
+            }
+            if (known * 2 < n || number.size() > 16) label.clear();  // a capture nobody noted (or a foreign graph): lay it out from the DAG
+            else {
+                nstreams = (int)number.size();
+                prio.assign(nstreams, 0);                            // a plan stream inherits the priority of the stream it stands for
+                for (auto& kv : number) { int p = 0; if (hipStreamGetPriority(kv.first, &p) == hipSuccess) prio[kv.second] = p; }
+            }
+        }
+        if (!unast_layout::plan_layout((int)n, deps, nstreams, lay, err, keep_chains, label.empty() ? nullptr : &label)) { unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: %s", err.c_str()); return 0; }
     }
     Plan* plan = new Plan();
     plan->events.assign(lay.event_node.size(), nullptr);
@@ -154,7 +205,9 @@ extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
     plan->streams.assign(nstreams, nullptr);
     plan->ends.assign(nstreams, nullptr);
     bool ok = true;
-    for (int t = 0; t < nstreams && ok; ++t) ok = hipStreamCreateWithFlags(&plan->streams[t], hipStreamNonBlocking) == hipSuccess;
+    for (int t = 0; t < nstreams && ok; ++t)
+        ok = (t < (int)prio.size() && prio[t] != 0 ? hipStreamCreateWithPriority(&plan->streams[t], hipStreamNonBlocking, prio[t])
+                                                   : hipStreamCreateWithFlags(&plan->streams[t], hipStreamNonBlocking)) == hipSuccess;
     for (size_t i = 0; i < plan->events.size() && ok; ++i) ok = hipEventCreateWithFlags(&plan->events[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&plan->begin, hipEventDisableTiming) == hipSuccess;
     for (int t = 0; t < nstreams && ok; ++t) ok = hipEventCreateWithFlags(&plan->ends[t], hipEventDisableTiming) == hipSuccess;
@@ -169,6 +222,11 @@ extern "C" int unast_graph_plan_info(int64_t handle, int* out4) {
     UNAST_REQUIRE(plan && out4, "unast_graph_plan_info: bad arguments");
     out4[0] = plan->kernels; out4[1] = plan->memsets; out4[2] = plan->memcpys; out4[3] = plan->cross_edges;
     return UNAST_OK;
+}
+
+extern "C" int unast_graph_plan_streams(int64_t handle) {
+    Plan* plan = (Plan*)(intptr_t)handle;
+    return plan ? (int)plan->streams.size() : -1;
 }
 
 extern "C" int unast_graph_plan_allreduces(int64_t handle) {

@@ -10,6 +10,10 @@
 // shorter-lived successor that happens to come first in the order -- a weight gradient issued in front of the input gradient that
 // continues the backward chain -- opens the branch instead.  Without it the long dependent chain of a step hops streams at every such
 // fork (one event hand-off each) and the side work takes over the stream its producer ran on.
+// label (round 4, optional): label[v] = the stream node v was CAPTURED on (-1: unknown), as the capture noted it launch by launch
+// (graph_exec.cpp, unast_capture_note).  Then the replay keeps the program's own stream structure -- the one the eager step runs with and
+// was tuned on -- instead of inventing one from the DAG: node v goes to stream label[v]; an unlabelled node (a launch that did not pass
+// through the C ABI) joins the stream of its first labelled successor, else of its first labelled dependency, else stream 0.
 #pragma once
 #include <algorithm>
 #include <functional>
@@ -32,7 +36,8 @@ struct Layout {
     int cross_edges = 0;
 };
 
-inline bool plan_layout(int n, const std::vector<std::vector<int>>& deps, int nstreams, Layout& out, std::string& err, bool keep_chains = false) {
+inline bool plan_layout(int n, const std::vector<std::vector<int>>& deps, int nstreams, Layout& out, std::string& err, bool keep_chains = false,
+                        const std::vector<int>* label = nullptr) {
     out = Layout();
     if (n <= 0 || nstreams < 1 || (int)deps.size() != n) { err = "bad arguments"; return false; }
     std::vector<std::vector<int>> succ(n);
@@ -62,6 +67,25 @@ inline bool plan_layout(int n, const std::vector<std::vector<int>>& deps, int ns
             const int v = order[oi];
             for (int s : succ[v]) way[v] = std::max(way[v], way[s] + 1);
         }
+    std::vector<int> fixed;                     // the stream of every node when labels are given
+    if (label) {
+        if ((int)label->size() != n) { err = "label array of the wrong size"; return false; }
+        fixed = *label;
+        for (int v = 0; v < n; ++v) if (fixed[v] >= nstreams) { err = "label beyond the stream count"; return false; }
+        for (int oi = n - 1; oi >= 0; --oi) {   // successors first
+            const int v = order[oi];
+            if (fixed[v] >= 0) continue;
+            int best = -1;
+            for (int u : succ[v]) if (fixed[u] >= 0 && (best < 0 || u < best)) best = u;
+            if (best >= 0) fixed[v] = fixed[best];
+        }
+        for (int oi = 0; oi < n; ++oi) {
+            const int v = order[oi];
+            if (fixed[v] >= 0) continue;
+            for (int d : deps[v]) if (fixed[d] >= 0) { fixed[v] = fixed[d]; break; }
+            if (fixed[v] < 0) fixed[v] = 0;
+        }
+    }
     std::vector<int> stream_of(n, -1), tail(nstreams, -1), remaining(n), event_of(n, -1), pos_in_order(n, 0);
     std::vector<long long> last_use(nstreams, -1);
     for (int i = 0; i < n; ++i) remaining[i] = (int)succ[i].size();
@@ -72,8 +96,8 @@ inline bool plan_layout(int n, const std::vector<std::vector<int>>& deps, int ns
     for (int oi = 0; oi < n; ++oi) {
         const int v = order[oi];
         pos_in_order[v] = oi;
-        int s = -1, best = -1;
-        for (int d : deps[v]) {
+        int s = label ? fixed[v] : -1, best = -1;
+        if (!label) for (int d : deps[v]) {
             const int sd = stream_of[d];
             if (tail[sd] != d || pos_in_order[d] <= best) continue;
             if (keep_chains) {            // does a later successor of d have more of the graph behind it?  Then the stream is kept for that one.

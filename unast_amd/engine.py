@@ -40,7 +40,8 @@ def _side(name):
     key = (torch.cuda.current_device(), _stream_group(name))
     s = _Streams.pool.get(key)
     if s is None:
-        s = _Streams.pool[key] = torch.cuda.Stream()
+        from . import config
+        s = _Streams.pool[key] = torch.cuda.Stream(priority=config.STREAM_PRIORITY.get(key[1], 0))
     return s
 
 
@@ -140,11 +141,20 @@ class _CaptureWaits:
 def capture_begins(origin):
     _CaptureWaits.origin = origin
     _CaptureWaits.edges = set()
+    # every library call from here on tells the library which stream its launch went to, so that the stream replay of the captured
+    # graph can keep this module's stream structure (include/unast_hip.h: unast_capture_note)
+    from . import _lib
+    l = _lib.lib()
+    l.unast_capture_reset()
+    note, cur = l.unast_capture_note, ops._stream
+    _lib.CAPTURE_NOTE = lambda: note(cur())
 
 
 def capture_ends():
     _CaptureWaits.origin = None
     _CaptureWaits.edges = set()
+    from . import _lib
+    _lib.CAPTURE_NOTE = None
 
 
 def wait(waiter, source_stream, event=None):

@@ -256,7 +256,7 @@ class GraphedTrainStep:
             if rec.plan:
                 info = (ctypes.c_int * 4)()
                 lib().unast_graph_plan_info(rec.plan, ctypes.addressof(info))
-                rec.plan_info = dict(mode="streams", kernels=info[0], memsets=info[1], memcpys=info[2], cross_stream_edges=info[3], streams=REPLAY_STREAMS)
+                rec.plan_info = dict(mode="streams", kernels=info[0], memsets=info[1], memcpys=info[2], cross_stream_edges=info[3], streams=lib().unast_graph_plan_streams(rec.plan))
                 nar = lib().unast_graph_plan_allreduces(rec.plan)
                 rec.plan_info["allreduces"] = nar
                 if nar > 0:
