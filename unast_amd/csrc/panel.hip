@@ -530,6 +530,170 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void panel_kernel(const PanelParam
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same row-panel GEMM on v_mfma_f32_32x32x16_bf16 (round 4; K = 256, N % 64 == 0, the plain / relu / relu + dropout / split epilogues;
+// selected by rows_per_wg = 2128).  An experiment the round-3 review and the knock-out table of DESIGN 5d-6 asked for: the 16x16x32 loop
+// is bound by vector ISSUE (an MFMA holds the SIMD's issue port 8 of its 16 cycles), the 32x32x16 form holds it 8 of 32 and reads half
+// the weight fragments per FLOP.  8 waves x 32 rows: wave = 2 rg + ch owns rows [32 rg, 32 rg + 32) of the 128-row panel and columns
+// [32 ch, 32 ch + 32) of every 64-column group; its activation rows stay in registers as B operands (lane: row l & 31, k = 16 ks + 8 (l >> 5)
+// .. + 7: 128 VGPRs for hi and lo), the weights are the A operand, read from the SAME tiled planes as above (a 32-column x 16-k fragment
+// is two 16-lane halves of two neighbouring sub-tiles), and a lane ends up with C[m = l & 31][n = 8 j + 4 (l >> 5) .. + 3], j = 0..3.
+// The sums over k are formed 16 at a time instead of 32: results differ from the 16x16x32 kernels in the last bits.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+__global__ __launch_bounds__(512, 1) void panel32_kernel(const PanelParams p) {
+    constexpr int KSTEPS = 8, NW = 8, NT = 64 * NW, ROWS = 128;
+    constexpr int NSUB = 8 * KSTEPS, GROUP = NSUB * PSUB, DMAX = NSUB / NW, RING = 2 * GROUP;
+    static_assert(RING >= ROWS * 1024, "the A image borrows the ring");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RING + 4096 + 1024];
+    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    __builtin_assume(wave >= 0 && wave < NW);
+    const int rg = wave >> 1, ch = wave & 1;
+    const int m_wg = blockIdx.x * ROWS, m_wave = m_wg + 32 * rg;
+    const uint32_t rbase = p.drop_thresh ? rng_stream_base(p.seed, p.stream) : 0u;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.W), 0, 0x7FFFFFF0, 0x00020000);
+    const int lane16 = lane * 16;
+    auto issue_group = [&](int cg) {
+#pragma unroll
+        for (int q = 0; q < DMAX; ++q) {
+            const int j = wave + NW * q;                              // this wave's sub-tile of the group: [plane][ct][ks]
+            const int pl = j / (4 * KSTEPS), rem = j - pl * (4 * KSTEPS);
+            const uint32_t soff = (uint32_t)pl * (uint32_t)p.plane_bytes + (uint32_t)(4 * cg * KSTEPS + rem) * PSUB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(smem + (cg & 1) * GROUP + j * PSUB), 16, lane16, (int)soff, 0, 0);
+        }
+    };
+    float* const sbias = reinterpret_cast<float*>(smem + RING);
+    const uint32_t sbias_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)sbias;
+    const bool bias_lds = p.bias != nullptr;
+    if (bias_lds) for (int i = t; i < 64 * p.ncg; i += NT) sbias[i] = (i < p.N) ? p.bias[i] : 0.f;
+
+    // the panel's rows as MFMA B fragments, split once
+    bf16x8_t ah[16], al[16];
+    {
+        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0x7FFFFFF0, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < ROWS / NW; ++q) {
+            const int r = wave * (ROWS / NW) + q;
+            const int row = min(m_wg + r, p.M - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(smem + r * 1024), 16, (lane ^ (r & 15)) << 4,
+                                                     (int)((uint32_t)row * (uint32_t)p.lda * 4u), 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned char* rowp = smem + (32 * rg + l31) * 1024;
+        const int sw = l31 & 15;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int c0 = 4 * ks + 2 * kh;
+            const float4 a = *reinterpret_cast<const float4*>(rowp + ((c0 ^ sw) << 4));
+            const float4 c = *reinterpret_cast<const float4*>(rowp + (((c0 + 1) ^ sw) << 4));
+            u32x2 h0, l0, h1, l1;
+            split4<3>(a, h0, l0);
+            split4<3>(c, h1, l1);
+            ah[ks] = __builtin_bit_cast(bf16x8_t, (u32x4){h0[0], h0[1], h1[0], h1[1]});
+            al[ks] = __builtin_bit_cast(bf16x8_t, (u32x4){l0[0], l0[1], l1[0], l1[1]});
+        }
+        __syncthreads();
+    }
+    issue_group(0);
+
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)min((size_t)0x7FFFFFF0, ((size_t)(p.M - 1) * p.ldc + p.N) * 4), 0x00020000);
+    const int m = m_wave + l31;
+    const uint32_t c_voff = ((uint32_t)m * (uint32_t)p.ldc + (uint32_t)(32 * ch + 4 * kh)) * 4u;
+    const uint32_t c_rkey = pcg_hash((uint32_t)m + rbase);
+    auto epilogue = [&](int cg, const f32x16_t& ac, auto act_t, auto drop_t, auto split_t) {
+        constexpr bool ACT = decltype(act_t)::value, DROP = decltype(drop_t)::value, SPLIT = decltype(split_t)::value;
+        f32x4 b4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (bias_lds) {
+            const uint32_t ba = sbias_lds + 4u * (uint32_t)(64 * cg + 32 * ch + 4 * kh);
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(b4[0]), "=&v"(b4[1]), "=&v"(b4[2]), "=&v"(b4[3]) : "v"(ba) : "memory");
+        }
+        const int soff = cg * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4] = {ac[4 * j] + b4[j][0], ac[4 * j + 1] + b4[j][1], ac[4 * j + 2] + b4[j][2], ac[4 * j + 3] + b4[j][3]};
+            if (ACT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) asm("v_max_f32 %0, 0, %1" : "=v"(v[r]) : "v"(v[r]));
+            }
+            if (DROP) {
+                const uint32_t n = (uint32_t)(64 * cg + 32 * ch + 8 * j + 4 * kh);
+                const uint32_t h01 = rng_pair(c_rkey, n), h23 = rng_pair(c_rkey, n + 2u);
+                v[0] = rng_keep_lo(h01, p.drop_thresh) ? v[0] * p.drop_scale : 0.f;
+                v[1] = rng_keep_hi(h01, p.drop_thresh) ? v[1] * p.drop_scale : 0.f;
+                v[2] = rng_keep_lo(h23, p.drop_thresh) ? v[2] * p.drop_scale : 0.f;
+                v[3] = rng_keep_hi(h23, p.drop_thresh) ? v[3] * p.drop_scale : 0.f;
+            }
+            u32x4 o;
+            if (SPLIT) {
+                const uint4 sc = split_chunk(make_float4(v[0], v[1], v[2], v[3]));
+                o = (u32x4){sc.x, sc.y, sc.z, sc.w};
+            } else {
+                o = (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, (int)(c_voff + (uint32_t)soff) + 32 * j, 0, 0);
+        }
+    };
+    const int epi_kind = p.drop_thresh ? 1 : p.out_split ? 2 : p.act == 1 ? 3 : 4;
+    int st_prev = 0, st_now = 0;
+    auto run_epilogue = [&](int cg, const f32x16_t& ac) {
+        using T = std::true_type; using F = std::false_type;
+        __builtin_amdgcn_s_setprio(1);
+        if (epi_kind == 1) epilogue(cg, ac, T{}, T{}, F{});
+        else if (epi_kind == 2) epilogue(cg, ac, F{}, F{}, T{});
+        else if (epi_kind == 3) epilogue(cg, ac, T{}, F{}, F{});
+        else epilogue(cg, ac, F{}, F{}, F{});
+        __builtin_amdgcn_s_setprio(0);
+        st_now += 4;
+    };
+    auto group_sync = [&](int cg) {
+        panel_wait_vm(st_prev);
+        __builtin_amdgcn_s_barrier();
+        if (cg + 1 < p.ncg) issue_group(cg + 1);
+    };
+    // weight fragment of (group, ks, plane): lane reads sub-tile (plane, ct = 2 ch + (l31 >> 4), ks / 2), unit (2 (ks & 1) + kh) * 16 + (l31 & 15)
+    const int lane_off = (2 * ch + (l31 >> 4)) * KSTEPS * PSUB + (kh * 16 + (l31 & 15)) * 16;
+    auto group_mma = [&](int cg, auto k0_t, auto k1_t, f32x16_t& ac) {
+        constexpr int K0 = decltype(k0_t)::value, K1 = decltype(k1_t)::value;
+        const unsigned char* base = smem + (cg & 1) * GROUP + lane_off;
+        bf16x8_t bf[2][2];
+        auto load_b = [&](int buf, int ks) {
+            bf[buf][0] = *reinterpret_cast<const bf16x8_t*>(base + (ks >> 1) * PSUB + (ks & 1) * 512);
+            bf[buf][1] = *reinterpret_cast<const bf16x8_t*>(base + 4 * KSTEPS * PSUB + (ks >> 1) * PSUB + (ks & 1) * 512);
+        };
+        load_b(K0 & 1, K0);
+#pragma unroll
+        for (int ks = K0; ks < K1; ++ks) {
+            if (ks + 1 < K1) load_b((ks + 1) & 1, ks + 1);
+            const bf16x8_t bh = bf[ks & 1][0], bl = bf[ks & 1][1];
+            ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[ks], ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[ks], ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[ks], ac, 0, 0, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using IH = std::integral_constant<int, 8>; using IK = std::integral_constant<int, 16>;
+    const bool late = ((wave >> 2) & 1) != 0;            // waves w and w + 4 share a SIMD: one runs its epilogue before the group's first k-step, the other in its middle
+    f32x16_t acc, pend;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; pend[i] = 0.f; }
+    for (int cg = 0; cg < p.ncg; ++cg) {
+        group_sync(cg);
+        if (!late && cg > 0) run_epilogue(cg - 1, pend);
+        group_mma(cg, I0{}, IH{}, acc);
+        if (late && cg > 0) run_epilogue(cg - 1, pend);
+        group_mma(cg, IH{}, IK{}, acc);
+        st_prev = st_now; st_now = 0;
+        pend = acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    }
+    run_epilogue(p.ncg - 1, pend);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Tiled bf16 planes of the weights.  One descriptor per 64 x 64 block of a destination matrix Wd[n][k] (n < N, k < K):
 //   {src offset (floats), src row stride, transposed, N, K, n0, k0, KSTEPS, dst hi offset (bytes), plane bytes}
 // transposed = 0: Wd[n][k] = src[n * ld + k]   (the forward operand: W as stored, [out][in])
@@ -886,7 +1050,7 @@ extern "C" int unast_panel_gemm(const float* A, int lda, const void* w_planes, i
     }
     UNAST_REQUIRE((K & 3) == 0 && K <= 256 && (lda & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)C) | ((uintptr_t)w_planes)) & 15) == 0,
                   "unast_panel_gemm: needs K %% 4 == 0, K <= 256, lda %% 4 == 0 and 16-byte aligned operands (K=%d lda=%d)", K, lda);
-    UNAST_REQUIRE(rows_per_wg == 0 || rows_per_wg == 64 || rows_per_wg == 128 || rows_per_wg == 1128, "unast_panel_gemm: rows_per_wg is 64, 128, 1128 (128 rows, 16 waves) or 0 (auto)");
+    UNAST_REQUIRE(rows_per_wg == 0 || rows_per_wg == 64 || rows_per_wg == 128 || rows_per_wg == 1128 || rows_per_wg == 2128, "unast_panel_gemm: rows_per_wg is 64, 128, 1128 (128 rows, 16 waves), 2128 (128 rows, 32x32x16 tiles) or 0 (auto)");
     UNAST_REQUIRE(!out_split || ((N & 3) == 0 && (ldc & 3) == 0), "unast_panel_gemm: out_split needs N %% 4 == 0 and ldc %% 4 == 0");
     const int ln = ln_gamma != nullptr;
     UNAST_REQUIRE(!ln || (N == 256 && ln_beta && Y && mean && rstd && (ldc & 3) == 0 && (ldy & 3) == 0 && !G && !act && !out_split &&
@@ -904,6 +1068,12 @@ extern "C" int unast_panel_gemm(const float* A, int lda, const void* w_planes, i
     p.gamma = ln_gamma; p.beta = ln_beta; p.Y = Y; p.ldy = ldy; p.mean = mean; p.rstd = rstd; p.eps = eps;
     // vector epilogue operands must be 16-byte addressable
     UNAST_REQUIRE((ldc & 3) == 0 || !out_split, "unast_panel_gemm: ldc");
+    if (rows_per_wg == 2128) {                           // the 32x32x16 form (experiment, see panel32_kernel)
+        UNAST_REQUIRE(K == 256 && (N & 63) == 0 && (ldc & 3) == 0 && !R && !G && !ln && !gate_bits && N <= 1024 && !(out_split && (act || drop_p > 0.f)) && !(drop_p > 0.f && act != 1),
+                      "unast_panel_gemm: rows_per_wg = 2128 serves K = 256, N %% 64 == 0 and the plain / relu / relu + dropout / split epilogues only");
+        hipLaunchKernelGGL(panel32_kernel, dim3((M + 127) / 128), dim3(512), 0, stream, p);
+        return unast_check_launch("unast_panel_gemm");
+    }
     const int ksteps = (K + 31) / 32;
     UNAST_REQUIRE(ksteps != 8 || K == 256, "unast_panel_gemm: 224 < K < 256 is not built (the 8-k-step form copies whole 1-KB activation rows by LDS-DMA; K=%d)", K);
     const int rt = rows_per_wg ? rows_per_wg : (M >= 16384 ? 128 : 64);
