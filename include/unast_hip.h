@@ -103,6 +103,12 @@ int64_t unast_layernorm_bwd_ws_floats(int rows, int C);
 
 /* Column sums sum[c] += sum_r x[r,c] (bias gradients of every nn.Linear/nn.Conv1d on the path). */
 int unast_colsum_f32(const float* x, int ldx, int rows, int C, float* sum, hipStream_t stream);
+/* The same sums in a FIXED order (row chunks in order, then the chunks in order; no atomics): what unast_amd.utils.set_deterministic(True)
+ * -- the parity mode of SURVEY.md Appendix C -- selects, together with unast_embed_bwd_det, the two-kernel attention backward and bias
+ * gradients taken by this function instead of the weight-gradient GEMM's atomics, so that two runs of a step, eager or replayed, agree
+ * to the bit in every fp32 sum.  ws: unast_colsum_det_ws_floats(rows, C) floats. */
+int unast_colsum_det(const float* x, int ldx, int rows, int C, float* sum, float* ws, int64_t ws_floats, hipStream_t stream);
+int64_t unast_colsum_det_ws_floats(int rows, int C);
 
 /* Train-mode BatchNorm1d + activation (1 relu, 2 tanh) + dropout over [rows=B*T, C]: TextPrenet.forward_fcn
  * (src/module.py:223-230) and SpeechPostnet.forward (src/module.py:162-165).  Updates running stats (momentum,
@@ -133,6 +139,10 @@ int unast_embed_fwd(const int64_t* ids, const float* E, float* out, int rows, in
 int unast_embed_bwd(const int64_t* ids, const float* dout, float* dE, int rows, int T, int D, int vocab, int shift_sos,
                     int padding_idx, float drop_p, unsigned int seed, unsigned int stream_id, float noise_p,
                     unsigned int noise_stream, hipStream_t stream);
+/* unast_embed_bwd with a fixed summation order (one workgroup per vocabulary id walks the rows in order; parity mode, see unast_colsum_det). */
+int unast_embed_bwd_det(const int64_t* ids, const float* dout, float* dE, int rows, int T, int D, int vocab, int shift_sos,
+                        int padding_idx, float drop_p, unsigned int seed, unsigned int stream_id, float noise_p,
+                        unsigned int noise_stream, hipStream_t stream);
 
 /* PositionalEncoding.forward (src/module.py:265-267): y = dropout(x*scale + pe[t]); bwd optionally gated by gate>0. */
 int unast_posenc_fwd(const float* x, const float* pe, float* y, int rows, int T, int D, float scale, float drop_p,

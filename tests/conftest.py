@@ -32,3 +32,12 @@ def panel_rows(request, monkeypatch):
         assert served[0] > 0 and served[1] > 0, "the panel kernels did not serve this test: %r" % (served,)
     else:
         assert served == [0, 0], "a small test shape reached the panel kernels through the shipped row gate: %r" % (served,)
+
+
+@pytest.fixture(autouse=True)
+def _fixed_sums_off_after_each_test():
+    """config.DETERMINISTIC_SUMS (utils.set_deterministic(..., fixed_sums=True)) selects slower, order-fixed kernels; a test that fails
+    while it is on must not leave the rest of the session on them (the parity tests are to pin the kernels the train step runs with)."""
+    yield
+    if "unast_amd.config" in sys.modules:
+        sys.modules["unast_amd.config"].DETERMINISTIC_SUMS = os.environ.get("UNAST_DETERMINISTIC_SUMS", "0") == "1"

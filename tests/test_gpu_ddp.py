@@ -26,7 +26,7 @@ dev = torch.device("cuda:0"); train.DEVICE = dev
 torch.cuda.set_device(dev)
 CM = os.environ.get("TEST_CM", "0") == "1"            # cross-model sub-step LAST (sp_steps = 0): its backward runs an encoder before its modality's decoder
 args = make_args(num_layers=1, ae_steps=1, sp_steps=0 if CM else 1, d_steps=1, cm_steps=1 if CM else 0)
-utils.set_seed(7); utils.set_deterministic(True)
+utils.set_seed(7); utils.set_deterministic(True, fixed_sums=os.environ.get("TEST_FIXED_SUMS", "0") == "1")      # fixed_sums: every fp32 sum in a fixed order
 _, _, model, opt, sched = train.initialize_model(args)
 opt.param_groups[0]["lr"] = 1e-3
 if os.environ.get("TEST_PERTURB"):                     # tools/replay_noise.py: how fast does one ulp in the weights grow over the steps?
@@ -140,11 +140,18 @@ def _run(tmp_path, world, port, **extra):
     assert all("rank %d ok" % r in outs[r] for r in range(world)), outs
 
 
-def _same(a, b):
+def _same(a, b, exact=False):
     """Two runs of the same two outer steps agree: the global norms of the exchanged gradients (a bucket reduced twice, not at
     all, or unscaled would move them by tens of percent) and the losses to accumulation-order noise; the parameters to a few
     Adam steps of that noise (the first updates are +-lr whatever the gradient's size, so near-zero gradients may flip sign)."""
+    import torch
     assert len(a["gnorms"]) == len(b["gnorms"])
+    if exact:            # runs made with TEST_FIXED_SUMS=1: every fp32 sum in a fixed order -> losses and parameters agree to the BIT (the norms
+        for x, y in zip(a["gnorms"], b["gnorms"]):            # are fp64 atomic sums: to 1e-12)
+            assert abs(x - y) <= 1e-12 * abs(y), (a["gnorms"], b["gnorms"])
+        assert a["losses"] == b["losses"], (a["losses"], b["losses"])
+        assert torch.equal(a["flat"], b["flat"]), float((a["flat"] - b["flat"]).abs().max())
+        return
     for x, y in zip(a["gnorms"], b["gnorms"]):
         assert abs(x - y) < 2e-4 * abs(y), (a["gnorms"], b["gnorms"])
     for k in a["losses"]:
@@ -161,15 +168,19 @@ def test_two_ranks_share_one_gpu_gloo(tmp_path):
     _run(tmp_path, 2, 29541, TEST_SAVE=str(tmp_path / "ov"))
     _run(tmp_path, 2, 29545, TEST_SAVE=str(tmp_path / "blk"), UNAST_DDP_OVERLAP="0")
     _same(torch.load(str(tmp_path / "ov") + ".0"), torch.load(str(tmp_path / "blk") + ".0"))
+    _run(tmp_path, 2, 29533, TEST_SAVE=str(tmp_path / "ovf"), TEST_FIXED_SUMS="1")           # ... and to the bit with every fp32 sum in a fixed order
+    _run(tmp_path, 2, 29535, TEST_SAVE=str(tmp_path / "blkf"), UNAST_DDP_OVERLAP="0", TEST_FIXED_SUMS="1")
+    for r in (0, 1):
+        _same(torch.load(str(tmp_path / "ovf") + ".%d" % r), torch.load(str(tmp_path / "blkf") + ".%d" % r), exact=True)
 
 
 def test_single_rank_nccl_executes_the_rccl_path(tmp_path):
     """World size 1 over the `nccl` backend (= RCCL on ROCm) with UNAST_DDP_FORCE=1: the collectives, the communication
     stream and its joins run for real on this one-GPU box, and the result equals the non-distributed step."""
     import torch
-    _run(tmp_path, 1, 29547, TEST_BACKEND="nccl", UNAST_DDP_FORCE="1", TEST_SAVE=str(tmp_path / "nccl"))
-    _run(tmp_path, 1, 29549, TEST_BACKEND="gloo", UNAST_DDP_FORCE="1", UNAST_DDP_OVERLAP="0", TEST_SAVE=str(tmp_path / "ref"))
-    _same(torch.load(str(tmp_path / "nccl") + ".0"), torch.load(str(tmp_path / "ref") + ".0"))
+    _run(tmp_path, 1, 29547, TEST_BACKEND="nccl", UNAST_DDP_FORCE="1", TEST_FIXED_SUMS="1", TEST_SAVE=str(tmp_path / "nccl"))
+    _run(tmp_path, 1, 29549, TEST_BACKEND="gloo", UNAST_DDP_FORCE="1", UNAST_DDP_OVERLAP="0", TEST_FIXED_SUMS="1", TEST_SAVE=str(tmp_path / "ref"))
+    _same(torch.load(str(tmp_path / "nccl") + ".0"), torch.load(str(tmp_path / "ref") + ".0"), exact=True)
 
 
 def test_two_ranks_cross_model_last_substep_overlap_equals_blocking(tmp_path):
@@ -177,9 +188,9 @@ def test_two_ranks_cross_model_last_substep_overlap_equals_blocking(tmp_path):
     decoder's, and the decoder still adds speech_m.prenet.* gradients into the encoder's bucket: the bucket may only travel after both
     (ddp._buckets_of).  Overlapped and blocking exchange must give the same gradients."""
     import torch
-    _run(tmp_path, 2, 29553, TEST_CM="1", TEST_SAVE=str(tmp_path / "ov"))
-    _run(tmp_path, 2, 29555, TEST_CM="1", TEST_SAVE=str(tmp_path / "blk"), UNAST_DDP_OVERLAP="0")
-    _same(torch.load(str(tmp_path / "ov") + ".0"), torch.load(str(tmp_path / "blk") + ".0"))
+    _run(tmp_path, 2, 29553, TEST_CM="1", TEST_FIXED_SUMS="1", TEST_SAVE=str(tmp_path / "ov"))
+    _run(tmp_path, 2, 29555, TEST_CM="1", TEST_FIXED_SUMS="1", TEST_SAVE=str(tmp_path / "blk"), UNAST_DDP_OVERLAP="0")
+    _same(torch.load(str(tmp_path / "ov") + ".0"), torch.load(str(tmp_path / "blk") + ".0"), exact=True)
 
 
 _STEP_BOUNDS = [1e-5, 1e-4, 5e-4, 2e-3, 2e-2]          # per step, see the comment in the test below
@@ -191,6 +202,11 @@ def test_single_rank_nccl_replayed_step_issues_the_collectives_from_cpp(tmp_path
     import torch
     _run(tmp_path, 1, 29557, TEST_BACKEND="nccl", UNAST_DDP_FORCE="1", TEST_GRAPH="1", TEST_SAVE=str(tmp_path / "g"))
     _run(tmp_path, 1, 29559, TEST_BACKEND="nccl", UNAST_DDP_FORCE="1", UNAST_NATIVE_COMM="0", TEST_STEPS="5", TEST_SAVE=str(tmp_path / "e"))
+    # ... and with every fp32 sum in a fixed order (utils.set_deterministic(True, fixed_sums=True)) the two agree to the BIT, losses and parameters
+    _run(tmp_path, 1, 29551, TEST_BACKEND="nccl", UNAST_DDP_FORCE="1", TEST_GRAPH="1", TEST_FIXED_SUMS="1", TEST_SAVE=str(tmp_path / "gf"))
+    _run(tmp_path, 1, 29543, TEST_BACKEND="nccl", UNAST_DDP_FORCE="1", UNAST_NATIVE_COMM="0", TEST_STEPS="5", TEST_FIXED_SUMS="1", TEST_SAVE=str(tmp_path / "ef"))
+    af, bf = torch.load(str(tmp_path / "gf") + ".0"), torch.load(str(tmp_path / "ef") + ".0")
+    assert af["losses"] == bf["losses"] and torch.equal(af["flat"], bf["flat"]), (af["losses"], bf["losses"], float((af["flat"] - bf["flat"]).abs().max()))
     a, b = torch.load(str(tmp_path / "g") + ".0"), torch.load(str(tmp_path / "e") + ".0")
     # Bounds per step, not one for all five: two EAGER runs of this worker already differ by 6e-8 / 8e-6 / 4e-5 / 2e-4 / 3e-3 in the
     # discriminator loss (atomic accumulation order; lr 1e-3 on a 2-utterance batch amplifies it ~10x per step), one ulp in the weights
@@ -228,10 +244,13 @@ def test_two_ranks_replayed_step_with_collectives_from_cpp(tmp_path, jitter):
     two ranks are shifted against each other at random: no hang, same result."""
     import torch
     _need_shim()
-    _run(tmp_path, 2, 29561 + int(jitter) % 7, TEST_GRAPH="1", UNAST_COMM_LIB=SHIM, UNAST_STREAM_JITTER=jitter, TEST_SAVE=str(tmp_path / "g"))
-    _run(tmp_path, 2, 29571 + int(jitter) % 7, UNAST_DDP_OVERLAP="0", TEST_STEPS="5", TEST_SAVE=str(tmp_path / "e"))
-    _close(torch.load(str(tmp_path / "g") + ".0"), torch.load(str(tmp_path / "e") + ".0"))
-    _close(torch.load(str(tmp_path / "g") + ".1"), torch.load(str(tmp_path / "e") + ".1"))
+    _run(tmp_path, 2, 29561 + int(jitter) % 7, TEST_GRAPH="1", UNAST_COMM_LIB=SHIM, UNAST_STREAM_JITTER=jitter, TEST_FIXED_SUMS="1", TEST_SAVE=str(tmp_path / "g"))
+    _run(tmp_path, 2, 29571 + int(jitter) % 7, UNAST_DDP_OVERLAP="0", TEST_STEPS="5", TEST_FIXED_SUMS="1", TEST_SAVE=str(tmp_path / "e"))
+    # every fp32 sum in a fixed order (TEST_FIXED_SUMS) and a two-rank sum is commutative: the replayed bucketed exchange and the blocking
+    # eager one agree to the BIT on both ranks -- a collective on stale or half-written gradients cannot hide under a noise bound
+    for r in (0, 1):
+        a, b = torch.load(str(tmp_path / "g") + ".%d" % r), torch.load(str(tmp_path / "e") + ".%d" % r)
+        assert a["losses"] == b["losses"] and torch.equal(a["flat"], b["flat"]), (r, a["losses"], b["losses"], float((a["flat"] - b["flat"]).abs().max()))
 
 
 def test_two_ranks_one_replays_one_runs_eagerly_with_other_shapes(tmp_path):
@@ -241,18 +260,19 @@ def test_two_ranks_one_replays_one_runs_eagerly_with_other_shapes(tmp_path):
     issue order on rank 1) and end with bit-equal parameters; the test communicator would fill a mismatched collective with NaN."""
     import torch
     _need_shim()
-    _run(tmp_path, 2, 29581, TEST_GRAPH="1", UNAST_COMM_LIB=SHIM, TEST_RANK_SHAPES="1", TEST_EAGER_RANK="1", TEST_SAVE=str(tmp_path / "g"))
-    _run(tmp_path, 2, 29583, UNAST_DDP_OVERLAP="0", TEST_STEPS="5", TEST_RANK_SHAPES="1", TEST_SAVE=str(tmp_path / "e"))
-    _close(torch.load(str(tmp_path / "g") + ".0"), torch.load(str(tmp_path / "e") + ".0"))
+    _run(tmp_path, 2, 29581, TEST_GRAPH="1", UNAST_COMM_LIB=SHIM, TEST_RANK_SHAPES="1", TEST_EAGER_RANK="1", TEST_FIXED_SUMS="1", TEST_SAVE=str(tmp_path / "g"))
+    _run(tmp_path, 2, 29583, UNAST_DDP_OVERLAP="0", TEST_STEPS="5", TEST_RANK_SHAPES="1", TEST_FIXED_SUMS="1", TEST_SAVE=str(tmp_path / "e"))
+    a, b = torch.load(str(tmp_path / "g") + ".0"), torch.load(str(tmp_path / "e") + ".0")       # (fixed summation order: to the bit)
+    assert a["losses"] == b["losses"] and torch.equal(a["flat"], b["flat"]), (a["losses"], b["losses"], float((a["flat"] - b["flat"]).abs().max()))
 
 
 def test_native_eager_exchange_two_ranks(tmp_path):
     """The eager step with the C ABI's communicator (event-chained unast_allreduce calls from ddp._issue) on two ranks == the blocking gloo exchange."""
     import torch
     _need_shim()
-    _run(tmp_path, 2, 29585, UNAST_COMM_LIB=SHIM, TEST_SAVE=str(tmp_path / "n"))
-    _run(tmp_path, 2, 29587, UNAST_DDP_OVERLAP="0", TEST_SAVE=str(tmp_path / "b"))
-    _same(torch.load(str(tmp_path / "n") + ".0"), torch.load(str(tmp_path / "b") + ".0"))
+    _run(tmp_path, 2, 29585, UNAST_COMM_LIB=SHIM, TEST_FIXED_SUMS="1", TEST_SAVE=str(tmp_path / "n"))
+    _run(tmp_path, 2, 29587, UNAST_DDP_OVERLAP="0", TEST_FIXED_SUMS="1", TEST_SAVE=str(tmp_path / "b"))
+    _same(torch.load(str(tmp_path / "n") + ".0"), torch.load(str(tmp_path / "b") + ".0"), exact=True)
 
 
 def test_bench_two_ranks_torchrun_replayed_collectives():

@@ -91,6 +91,29 @@ def test_graph_replay_and_eager_steps_agree(use_disc, replay, monkeypatch):
     assert float(d.max()) <= 8 * 4e-4 and float((d > 2e-5).float().mean()) < 0.3, (float(d.max()), float((d > 2e-5).float().mean()))
 
 
+@pytest.mark.parametrize("use_disc", [True, False])
+def test_fixed_summation_order_makes_runs_agree_to_the_bit(use_disc, monkeypatch):
+    """utils.set_deterministic(True, fixed_sums=True): every fp32 sum of the step is formed in a fixed order (two-kernel attention
+    backward, ordered bias / embedding gradients, ungrouped weight gradients; ops.deterministic_sums).  Then six steps at lr = 4e-4 --
+    the setting in which rounding noise grows tenfold per step otherwise (profiles/r04_replay_noise.txt) -- give (a) the SAME losses and
+    parameters, bit for bit, in two eager runs, and (b) the same in the captured and stream-replayed run as in the eager one: any race
+    or mis-ordered replay shows up as a difference instead of hiding under a noise bound."""
+    from unast_amd import utils, graphed
+    monkeypatch.setattr(graphed, "REPLAY", "streams")
+    utils.set_deterministic(True, fixed_sums=True)
+    try:
+        (la, pa, sa, lra) = _run_steps(False, use_disc, 4e-4)
+        (lb, pb, sb, lrb) = _run_steps(False, use_disc, 4e-4)
+        (lc, pc, sc, lrc) = _run_steps(True, use_disc, 4e-4)
+    finally:
+        utils.set_deterministic(True, fixed_sums=False)
+    assert la == lb, ("two eager runs", {k: (la[k], lb[k]) for k in la if la[k] != lb[k]})
+    assert torch.equal(pa, pb), float((pa - pb).abs().max())
+    assert sa == sc and lra == lrc
+    worst = max(abs(x - y) / max(1.0, abs(x)) for k in la for x, y in zip(la[k], lc[k]))
+    assert worst == 0.0 and torch.equal(pa, pc), ("eager vs replayed", worst, float((pa - pc).abs().max()))
+
+
 def test_graph_replays_draw_fresh_masks_and_permutations():
     """With the RNG sites on, replays of ONE captured graph on the SAME batch give different losses (dropout / noise /
     SpecAugment masks and the discriminator's row permutation follow the RNG epoch in device memory), all finite, and the

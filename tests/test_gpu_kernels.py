@@ -417,6 +417,42 @@ def test_lstm_fwd_bwd_matches_torch_packed():
     assert relerr(dg2.sum(0), torch.cat([lstm.bias_ih_l0.grad, lstm.bias_ih_l0_reverse.grad])) < 5e-5
 
 
+def test_order_fixed_column_sums_and_embedding_gradient():
+    """unast_colsum_det / unast_embed_bwd_det (config.DETERMINISTIC_SUMS): the same sums as the atomic kernels, to fp32 rounding against
+    fp64, and bit-identical from run to run."""
+    from unast_amd import config, ops
+    g = torch.Generator().manual_seed(3)
+    for rows, C in ((5000, 256), (777, 46), (1, 81), (25600, 1024)):
+        x = torch.randn(rows, C, generator=g).to(D)
+        ref = x.double().sum(0).cpu()
+        outs = []
+        for rep in range(2):
+            out = torch.full((C,), 0.5, device=D)
+            config.DETERMINISTIC_SUMS = True
+            try:
+                ops.colsum(x, out)
+            finally:
+                config.DETERMINISTIC_SUMS = False
+            outs.append(out.clone())
+            assert relerr(out - 0.5, ref) < 2e-6, (rows, C)
+        assert torch.equal(outs[0], outs[1])
+        a = torch.full((C,), 0.5, device=D); ops.colsum(x, a)
+        assert relerr(a, outs[0].cpu()) < 2e-6
+    V, Dm, B, T = 46, 256, 6, 37
+    ids = torch.randint(0, V, (B, T), generator=g).to(D)
+    dout = torch.randn(B * T, Dm, generator=g).to(D)
+    for shift, kw in ((-1, {}), (1, {}), (-1, dict(drop_p=0.2, seed=5, stream_id=3, noise_p=0.1, noise_stream=4))):
+        a = torch.zeros(V, Dm, device=D); b = torch.zeros(V, Dm, device=D); c = torch.zeros(V, Dm, device=D)
+        ops.embed_bwd(ids, dout, a, T, shift_sos=shift, **kw)
+        config.DETERMINISTIC_SUMS = True
+        try:
+            ops.embed_bwd(ids, dout, b, T, shift_sos=shift, **kw)
+            ops.embed_bwd(ids, dout, c, T, shift_sos=shift, **kw)
+        finally:
+            config.DETERMINISTIC_SUMS = False
+        assert torch.equal(b, c) and relerr(a, b.cpu()) < 2e-6 and float(b[0].abs().max()) == 0.0, (shift, kw)
+
+
 def test_leaky_dropout_and_disc_gather():
     from unast_amd import ops
     g = torch.Generator().manual_seed(8)

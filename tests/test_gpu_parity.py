@@ -67,9 +67,18 @@ def test_forward_matches_reference_golden(golden_dir, name, panel_rows):
     assert any(not torch.equal(v, model.state_dict()[k]) for k, v in bn_before.items()), "train-mode BN must update running stats"
 
 
+@pytest.fixture(params=[False, True], ids=["atomics", "fixed-sums"])
+def fixed_sums(request, monkeypatch):
+    """The order-fixed forms (utils.set_deterministic(True, fixed_sums=True): two-kernel attention backward, unast_colsum_det bias
+    gradients, unast_embed_bwd_det, ungrouped weight gradients) against the same reference fixture as the shipped ones."""
+    from unast_amd import config
+    monkeypatch.setattr(config, "DETERMINISTIC_SUMS", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("joint", [False, True], ids=["substeps", "joint"])
 @pytest.mark.parametrize("name", ["step_b1_t40_m200_l4", "step_b4_t24_m64_l2", "step_b4_t24_m64_l4_lr0"])
-def test_full_step_matches_reference_golden(golden_dir, name, panel_rows, joint):
+def test_full_step_matches_reference_golden(golden_dir, name, panel_rows, joint, fixed_sums):
     """joint: the generator phase as train.train_gen_joint_step (one forward and one backward over both sub-steps, encoders and
     discriminator batched over the two) instead of train_ae_step + train_sp_step -- against the SAME reference fixture: seven losses,
     per-tensor gradient norms, BatchNorm running statistics after two updates each, AdamW deltas."""

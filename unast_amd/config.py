@@ -50,6 +50,9 @@ STREAM_GROUPS = dict(kv.split(":") for kv in os.environ.get("UNAST_STREAM_GROUPS
 # with the priorities of the streams the nodes were captured on (csrc/graph_exec.cpp).
 STREAM_PRIORITY = {k: int(v) for k, v in (kv.split(":") for kv in os.environ.get("UNAST_STREAM_PRIO", "").split(",") if ":" in kv)}
 
+# Fixed summation order of every fp32 sum (ops.deterministic_sums; utils.set_deterministic(True, fixed_sums=True) sets it).
+DETERMINISTIC_SUMS = os.environ.get("UNAST_DETERMINISTIC_SUMS", "0") == "1"
+
 # Weight gradients of one backward closure (an attention sub-layer's out-proj + in-proj, an FFN's two linears, ...) go out as
 # ONE grouped launch (csrc/gemm.hip gemm_group_kernel) instead of one split-K launch + one reduction each; 0 = one by one.
 WGRAD_GROUP = os.environ.get("UNAST_WGRAD_GROUP", "1") != "0"

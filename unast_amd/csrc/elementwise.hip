@@ -320,6 +320,41 @@ extern "C" int unast_embed_fwd(const int64_t* ids, const float* E, float* out, i
     return unast_check_launch("unast_embed_fwd");
 }
 
+// The same gradient with a FIXED summation order (unast_embed_bwd_det; parity / reproducibility mode): one workgroup per vocabulary id
+// walks all rows in order, thread = column, no atomics.  (The kernel above collects its hits in arrival order and adds chunk sums with
+// atomics: the result depends on scheduling in its last bits.)
+__global__ __launch_bounds__(256) void embed_bwd_det_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                                            float* __restrict__ dE, int rows, int T, int D, int shift_sos, int padding_idx,
+                                                            uint32_t drop_thresh, float drop_scale, uint32_t seed, uint32_t stream,
+                                                            uint32_t noise_thresh, uint32_t noise_stream) {
+    const int v = blockIdx.x;
+    if (v == padding_idx) return;
+    for (int c0 = 0; c0 < D; c0 += 256) {
+        const int c = c0 + threadIdx.x;
+        float acc = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            int64_t id;
+            if (shift_sos >= 0) { const int t = r % T; id = (t == 0) ? (int64_t)shift_sos : ids[r - 1]; }
+            else id = ids[r];
+            if (id != v || c >= D) continue;                       // (the first test is uniform)
+            float g = dout[(size_t)r * D + c];
+            if (drop_thresh) g = rng_keep(rng_row_key(seed, stream, (uint32_t)r), c, drop_thresh) ? g * drop_scale : 0.f;
+            if (noise_thresh && !rng_keep(rng_row_key(seed, noise_stream, (uint32_t)r), 0u, noise_thresh)) g = 0.f;
+            acc += g;
+        }
+        if (c < D) dE[(size_t)v * D + c] += acc;
+    }
+}
+
+extern "C" int unast_embed_bwd_det(const int64_t* ids, const float* dout, float* dE, int rows, int T, int D, int vocab, int shift_sos,
+                                   int padding_idx, float drop_p, unsigned int seed, unsigned int stream_id, float noise_p,
+                                   unsigned int noise_stream, hipStream_t stream) {
+    UNAST_REQUIRE(ids && dout && dE && rows > 0 && T > 0 && vocab > 0, "unast_embed_bwd_det: bad arguments");
+    hipLaunchKernelGGL(embed_bwd_det_kernel, dim3(vocab), dim3(256), 0, stream, ids, dout, dE, rows, T, D, shift_sos, padding_idx,
+                       drop_threshold(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, stream_id, drop_threshold(noise_p), noise_stream);
+    return unast_check_launch("unast_embed_bwd_det");
+}
+
 extern "C" int unast_embed_bwd(const int64_t* ids, const float* dout, float* dE, int rows, int T, int D, int vocab, int shift_sos,
                                int padding_idx, float drop_p, unsigned int seed, unsigned int stream_id, float noise_p,
                                unsigned int noise_stream, hipStream_t stream) {

@@ -463,6 +463,43 @@ static int colsum_geometry(int rows, int C, int* blocks, int* rpb) {
     return 0;
 }
 
+// Column sums with a FIXED summation order (unast_colsum_det; parity / reproducibility mode): every workgroup writes the partial sums
+// of its row chunk (rows in order, thread = column), a second launch adds the chunks in order.  No atomics.
+__global__ __launch_bounds__(256) void colsum_det_part_kernel(const float* __restrict__ x, int ldx, int rows, int C, int rows_per_block, float* __restrict__ part) {
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int r = r0; r < r1; ++r) a += x[(size_t)r * ldx + c];
+        part[(size_t)blockIdx.x * C + c] = a;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_det_final_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ sum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = sum[c];
+    for (int b = 0; b < blocks; ++b) a += part[(size_t)b * C + c];
+    sum[c] = a;
+}
+static void colsum_det_geometry(int rows, int* blocks, int* rpb) {
+    int b = grid_for(rows, 64, 512);
+    *rpb = (rows + b - 1) / b;
+    *blocks = (rows + *rpb - 1) / *rpb;
+}
+extern "C" int64_t unast_colsum_det_ws_floats(int rows, int C) {
+    int blocks, rpb;
+    colsum_det_geometry(rows, &blocks, &rpb);
+    return (int64_t)blocks * C;
+}
+extern "C" int unast_colsum_det(const float* x, int ldx, int rows, int C, float* sum, float* ws, int64_t ws_floats, hipStream_t stream) {
+    UNAST_REQUIRE(x && sum && ws && rows > 0 && C > 0, "unast_colsum_det: bad arguments");
+    int blocks, rpb;
+    colsum_det_geometry(rows, &blocks, &rpb);
+    UNAST_REQUIRE(ws_floats >= (int64_t)blocks * C, "unast_colsum_det: workspace too small (need %lld floats)", (long long)blocks * C);
+    hipLaunchKernelGGL(colsum_det_part_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, rows, C, rpb, ws);
+    hipLaunchKernelGGL(colsum_det_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, blocks, C, sum);
+    return unast_check_launch("unast_colsum_det");
+}
+
 extern "C" int unast_colsum_f32(const float* x, int ldx, int rows, int C, float* sum, hipStream_t stream) {
     UNAST_REQUIRE(x && sum, "unast_colsum_f32: null pointer");
     int blocks, rpb;

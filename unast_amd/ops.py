@@ -29,6 +29,16 @@ _F32 = torch.float32
 _LN_WS = {}
 
 
+def deterministic_sums():
+    """True with config.DETERMINISTIC_SUMS (utils.set_deterministic(True, fixed_sums=True), or UNAST_DETERMINISTIC_SUMS=1): every fp32 sum
+    of the step is then formed in a fixed order -- the two-kernel attention backward instead of the one-pass kernel's dQ atomics, bias
+    gradients by unast_colsum_det instead of the weight-gradient GEMM's row-sum atomics, unast_embed_bwd_det, ungrouped weight gradients --
+    so that two runs of a step, eager or replayed, agree to the bit.  (fp64 accumulators -- BatchNorm statistics, loss sums, the gradient
+    norm -- stay atomic: their order only moves bits far below fp32 resolution.)  Off by default, also in the parity mode: the golden and
+    oracle tests are to pin the kernels the train step runs with."""
+    return bool(config.DETERMINISTIC_SUMS)
+
+
 def _f32(t, name):
     if t is None:
         return
@@ -237,6 +247,12 @@ def _linear_wgrad_now(dy2d, x2d, dW, db=None):
     M, N = dy2d.shape
     K = x2d.shape[1]
     sk = _splitk_for(N, K, M)
+    if db is not None and deterministic_sums():          # the bias gradient in a fixed order, behind the weight gradient on its stream
+        def both():
+            gemm(OP_RC, OP_RC, dy2d, dy2d.stride(0), x2d, x2d.stride(0), dW, dW.stride(0), N, K, M, beta=1, splitk=sk)
+            colsum(dy2d, db)
+        _on_wgrad_stream(both, M, dW.data_ptr(), dy2d, x2d)
+        return dW
     _on_wgrad_stream(lambda: gemm(OP_RC, OP_RC, dy2d, dy2d.stride(0), x2d, x2d.stride(0), dW, dW.stride(0), N, K, M, beta=1, splitk=sk,
                                   rowsum_a=db), M, dW.data_ptr(), dy2d, x2d)
     return dW
@@ -300,7 +316,10 @@ def _flush_wgrads(items):
     for off, its in groups.items():
         for i in range(0, len(its), GROUP_MAX):
             chunk = its[i:i + GROUP_MAX]
-            if len(chunk) == 1:
+            if deterministic_sums():                       # (the grouped kernel takes the bias gradients by atomics)
+                for it in chunk:
+                    _linear_wgrad_now(*it)
+            elif len(chunk) == 1:
                 _linear_wgrad_now(*chunk[0])
             else:
                 _launch_group(chunk, off)
@@ -412,6 +431,13 @@ def conv_wgrad(dy3d, x3d, dWp, pad_left, db=None):
     B, T, Cout = dy3d.shape
     Cin = x3d.shape[2]
     sk = _splitk_for(Cout, 5 * Cin, B * T)
+    if db is not None and deterministic_sums() and dy3d.is_contiguous():
+        def both():
+            gemm(OP_RC, OP_RC_CONV_WGRAD, dy3d, dy3d.stride(1), x3d, x3d.stride(1), dWp, 5 * Cin, Cout, 5 * Cin, B * T,
+                 conv=(T, 0, Cin, pad_left), beta=1, splitk=sk)
+            colsum(dy3d.view(B * T, Cout), db)
+        _on_wgrad_stream(both, B * T, dWp.data_ptr(), dy3d, x3d)
+        return dWp
     _on_wgrad_stream(lambda: gemm(OP_RC, OP_RC_CONV_WGRAD, dy3d, dy3d.stride(1), x3d, x3d.stride(1), dWp, 5 * Cin, Cout, 5 * Cin, B * T,
                                   conv=(T, 0, Cin, pad_left), beta=1, splitk=sk, rowsum_a=db), B * T, dWp.data_ptr(), dy3d, x3d)
     return dWp
@@ -427,11 +453,12 @@ def attn_fwd(Q, K, V, O, LSE, lens_k, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, 
 
 def attn_bwd(Q, K, V, O, dO, LSE, delta_ws, dQ, dK, dV, lens_k, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, stream_id=0, nsplit=None, qkv_split=False, lens_q=None):
     """lens_q (int32 [B], one-pass backward only): queries t >= lens_q[b] have a zero dO by the caller's guarantee; their tiles are skipped."""
+    fused = config.ATTN_FUSED_BWD and not deterministic_sums()          # (the one-pass kernel adds dQ with fp32 atomics)
     check(lib().unast_attn_bwd(nsplit or config.NSPLIT, _p(Q), Q.stride(0), _p(K), K.stride(0), _p(V), V.stride(0), _p(O), O.stride(0),
                                _p(dO), dO.stride(0), _p(LSE), _p(delta_ws), _p(dQ), dQ.stride(0), _p(dK), dK.stride(0), _p(dV),
                                dV.stride(0), _p(lens_k), B, H, Tq, Tk, 64, int(causal), 0.125, drop_p, seed & 0xFFFFFFFF, stream_id,
-                               (2 if config.ATTN_BWD_TERMS == 2 else 1) if config.ATTN_FUSED_BWD else 0, int(qkv_split),
-                               _p(lens_q) if config.ATTN_FUSED_BWD else None, _stream()), "unast_attn_bwd")
+                               (2 if config.ATTN_BWD_TERMS == 2 else 1) if fused else 0, int(qkv_split),
+                               _p(lens_q) if fused else None, _stream()), "unast_attn_bwd")
 
 
 # ---- normalisation -----------------------------------------------------------------------------------------
@@ -457,6 +484,11 @@ def layernorm_bwd(dy, z, gamma, mean, rstd, dz, dz_drop=None, dgamma=None, dbeta
 
 def colsum(x2d, out):
     rows, C = x2d.shape
+    if deterministic_sums():
+        ws_n = lib().unast_colsum_det_ws_floats(rows, C)
+        ws = torch.empty(ws_n, dtype=torch.float32, device=x2d.device)
+        check(lib().unast_colsum_det(_p(x2d), x2d.stride(0), rows, C, _p(out), _p(ws), ws_n, _stream()), "unast_colsum_det")
+        return
     check(lib().unast_colsum_f32(_p(x2d), x2d.stride(0), rows, C, _p(out), _stream()), "unast_colsum_f32")
 
 
@@ -488,8 +520,9 @@ def embed_fwd(ids, E, out, T, shift_sos=-1, drop_p=0.0, seed=0, stream_id=0, noi
 
 def embed_bwd(ids, dout, dE, T, shift_sos=-1, drop_p=0.0, seed=0, stream_id=0, noise_p=0.0, noise_stream=0, padding_idx=0):
     rows = ids.numel()
-    check(lib().unast_embed_bwd(_p(ids), _p(dout), _p(dE), rows, T, dE.shape[1], dE.shape[0], shift_sos, padding_idx, drop_p,
-                                seed & 0xFFFFFFFF, stream_id, noise_p, noise_stream, _stream()), "unast_embed_bwd")
+    fn = lib().unast_embed_bwd_det if deterministic_sums() else lib().unast_embed_bwd
+    check(fn(_p(ids), _p(dout), _p(dE), rows, T, dE.shape[1], dE.shape[0], shift_sos, padding_idx, drop_p,
+             seed & 0xFFFFFFFF, stream_id, noise_p, noise_stream, _stream()), "unast_embed_bwd")
 
 
 def posenc_fwd(x2d, pe, y, T, scale, drop_p=0.0, seed=0, stream_id=0):

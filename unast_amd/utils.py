@@ -34,10 +34,16 @@ def next_seed():
     return x
 
 
-def set_deterministic(flag=True):
+def set_deterministic(flag=True, fixed_sums=None):
     """Parity mode: identity permutation in discriminator_shuffle_batch and no SpecAugment (dropout is governed by the
-    configured rates / model.eval()).  Mirrors the oracle harness of SURVEY.md Appendix C."""
+    configured rates / model.eval()).  Mirrors the oracle harness of SURVEY.md Appendix C.
+    fixed_sums (True / False; None leaves it as it is): additionally form every fp32 sum of the step in a fixed order
+    (config.DETERMINISTIC_SUMS, ops.deterministic_sums): two runs of a step, eager or replayed, then agree to the bit -- at the
+    price of slower kernels (two-kernel attention backward, ungrouped weight gradients, ordered column sums)."""
     _RNG["deterministic"] = bool(flag)
+    if fixed_sums is not None:
+        from . import config
+        config.DETERMINISTIC_SUMS = bool(fixed_sums)
 
 
 def is_deterministic():
