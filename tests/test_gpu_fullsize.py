@@ -351,3 +351,49 @@ def test_replayed_soak_over_two_ragged_shapes_stays_finite_and_learns():
         assert stepper.stats["replays"] >= 4, stepper.stats
     finally:
         utils.set_deterministic(True)
+
+
+def test_full_size_replayed_steps_equal_eager_steps_to_the_bit():
+    """Eight steps alternating between config 5's shape (B=32 / T_text=300 / T_mel=2000) and B=16 / 180 / 800, ragged lengths, once through
+    train.train_step and once through GraphedTrainStep (eager, captured, stream-replayed), with every fp32 sum in a fixed order
+    (utils.set_deterministic(True, fixed_sums=True)): the seven losses of every step and the parameters agree to the BIT.  The race of
+    DESIGN 5c-8b opened its window only at this size; with a fixed summation order a dependency that holds by timing alone cannot hide
+    under a noise bound here either."""
+    from collections import defaultdict
+    from unast_amd import train, utils
+    from unast_amd.configs import make_args
+    from unast_amd.engine import join_streams
+    from unast_amd.graphed import GraphedTrainStep
+    from unast_amd.portable import synth_batch
+    train.DEVICE = D
+    shapes = ((32, 300, 2000), (16, 180, 800))
+    data = {s: [tuple(torch.from_numpy(x).to(D) for x in synth_batch(*s, seed=k, ragged=True)) for k in range(2)] for s in shapes}
+    utils.set_deterministic(True, fixed_sums=True)
+    try:
+        res = []
+        for graphed in (False, True):
+            args = make_args(num_layers=4, ae_steps=1, sp_steps=1, d_steps=1, cm_steps=0, warmup_steps=200)
+            utils.set_seed(0)
+            _, _, model, opt, sched = train.initialize_model(args)
+            stepper = GraphedTrainStep(model, opt, sched, args) if graphed else None
+            losses = defaultdict(list)
+            for i in range(8):
+                batch = data[shapes[(i // 3) % 2]][i % 2]
+                b = dict(unsup=[batch], sup=[batch], disc=[batch], cm=[])
+                if graphed:
+                    stepper(losses, b, i)
+                else:
+                    train.train_step(losses, model, opt, sched, b, i, args, defer_d_phase=True)
+            if graphed:
+                stepper.flush(losses)
+                assert stepper.stats["replays"] >= 1, stepper.stats
+            join_streams()
+            torch.cuda.synchronize()
+            res.append(({k: [float(x) for x in v] for k, v in losses.items()}, model._store().flat.detach().clone()))
+        (la, pa), (lb, pb) = res
+        assert bool(torch.isfinite(pa).all())
+        assert la == lb, {k: (la[k], lb[k]) for k in la if la[k] != lb[k]}
+        assert torch.equal(pa, pb), float((pa - pb).abs().max())
+    finally:
+        utils.set_deterministic(True, fixed_sums=False)
+
