@@ -383,6 +383,14 @@ int unast_graph_plan_allreduce_counts(int64_t plan, long long* out, int n);
  * plan_streams: how many streams the plan uses. */
 int unast_capture_reset(void);
 int unast_capture_note(hipStream_t stream);
+/* Pruning what a side stream inherits from the capture's origin stream (unast_amd/engine.py relays every hand-off between two side streams
+ * through the origin: ROCm 7.2 cannot end a capture in which two side streams waited on each other; the origin's dependency set therefore
+ * accumulates the producers of all hand-offs).  get_deps: the graph nodes the stream's next captured node would depend on (their number;
+ * -1 not capturing, -2 more than cap).  prune: drops from the stream's dependency set every node noted (unast_capture_note) on ANOTHER side
+ * stream unless it is listed in `keep` -- nodes of the stream itself, of `origin`, and un-noted nodes always stay; returns how many were
+ * dropped (hipStreamUpdateCaptureDependencies). */
+int unast_capture_get_deps(hipStream_t stream, void** out, int cap);
+int unast_capture_prune(hipStream_t stream, hipStream_t origin, void** keep, int nkeep);
 int unast_graph_plan_streams(int64_t plan);
 
 /* Data-parallel gradient exchange over RCCL / xGMI (csrc/comm.cpp).  New with respect to the reference, which is single-device

@@ -53,6 +53,10 @@ STREAM_PRIORITY = {k: int(v) for k, v in (kv.split(":") for kv in os.environ.get
 # Fixed summation order of every fp32 sum (ops.deterministic_sums; utils.set_deterministic(True, fixed_sums=True) sets it).
 DETERMINISTIC_SUMS = os.environ.get("UNAST_DETERMINISTIC_SUMS", "0") == "1"
 
+# While a HIP graph is being captured, a backward segment drops the dependencies its stream inherited from the origin stream's relay that
+# are not the producers of its own incoming gradients (engine._Segment._backward; include/unast_hip.h unast_capture_prune).  0 = round-2 form.
+CAPTURE_PRUNE = os.environ.get("UNAST_CAPTURE_PRUNE", "1") != "0"
+
 # Weight gradients of one backward closure (an attention sub-layer's out-proj + in-proj, an FFN's two linears, ...) go out as
 # ONE grouped launch (csrc/gemm.hip gemm_group_kernel) instead of one split-K launch + one reduction each; 0 = one by one.
 WGRAD_GROUP = os.environ.get("UNAST_WGRAD_GROUP", "1") != "0"

@@ -81,6 +81,48 @@ extern "C" int unast_capture_note(hipStream_t stream) {
     return UNAST_OK;
 }
 
+// Inherited dependencies of a side stream, pruned (engine._Segment._backward).  Inside a capture every hand-off between two side streams is
+// relayed by the origin stream, whose dependency set therefore accumulates the producers of ALL hand-offs so far -- and a side stream that
+// syncs with the origin inherits them all (1.6 ms of the replayed step).  At the start of a backward segment the only foreign
+// producers it can need are those of its incoming gradients (`keep`: their producers' tail nodes, noted when they were produced): every
+// other node in the stream's dependency set that was captured on ANOTHER side stream is dropped.  Nodes of the stream itself, of the
+// origin, and nodes nobody noted (launches that did not pass through this library) always stay.
+extern "C" int unast_capture_prune(hipStream_t stream, hipStream_t origin, void** keep, int nkeep) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipGraph_t g = nullptr;
+    const hipGraphNode_t* dep = nullptr;
+    size_t nd = 0;
+    if (hipStreamGetCaptureInfo_v2(stream, &st, &id, &g, &dep, &nd) != hipSuccess || st != hipStreamCaptureStatusActive || nd == 0) return 0;
+    std::vector<hipGraphNode_t> kept;
+    {
+        std::lock_guard<std::mutex> lock(g_label_mutex);
+        for (size_t i = 0; i < nd; ++i) {
+            auto it = g_labels.find(dep[i]);
+            bool stay = it == g_labels.end() || it->second == stream || it->second == origin;
+            for (int k = 0; k < nkeep && !stay; ++k) stay = keep[k] == (void*)dep[i];
+            if (stay) kept.push_back(dep[i]);
+        }
+    }
+    if (kept.empty() || kept.size() == nd) return 0;
+    const hipError_t e = hipStreamUpdateCaptureDependencies(stream, kept.data(), kept.size(), hipStreamSetCaptureDependencies);
+    if (e != hipSuccess) { unast_set_error(UNAST_ERR_LAUNCH, "unast_capture_prune: hipStreamUpdateCaptureDependencies failed (%d: %s)", (int)e, hipGetErrorString(e)); return -1; }
+    return (int)(nd - kept.size());
+}
+
+// The capturing stream's current dependency set (the nodes its next captured node will depend on); -1 when the stream is not capturing.
+extern "C" int unast_capture_get_deps(hipStream_t stream, void** out, int cap) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipGraph_t g = nullptr;
+    const hipGraphNode_t* dep = nullptr;
+    size_t nd = 0;
+    if (hipStreamGetCaptureInfo_v2(stream, &st, &id, &g, &dep, &nd) != hipSuccess || st != hipStreamCaptureStatusActive) return -1;
+    if ((int)nd > cap) return -2;
+    for (size_t i = 0; i < nd; ++i) out[i] = (void*)dep[i];
+    return (int)nd;
+}
+
 extern "C" int64_t unast_graph_plan_create(void* graph_handle, int nstreams) {
     hipGraph_t graph = (hipGraph_t)graph_handle;
     if (!graph || nstreams < 1 || nstreams > 16) { unast_set_error(UNAST_ERR_ARG, "unast_graph_plan_create: bad arguments"); return 0; }

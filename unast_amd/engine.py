@@ -146,6 +146,7 @@ def capture_begins(origin):
     from . import _lib
     l = _lib.lib()
     l.unast_capture_reset()
+    _GradTail.clear()
     note, cur = l.unast_capture_note, ops._stream
     _lib.CAPTURE_NOTE = lambda: note(cur())
 
@@ -191,6 +192,33 @@ class _ViaOrigin(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g
+
+
+PRUNED = [0]            # inherited dependencies dropped by _Segment._backward while capturing (tests look at it)
+_GradTail = {}          # while capturing: storage address of a gradient -> the graph nodes that produced it (tail of its stream then)
+
+
+def _prune_on():
+    from . import config
+    return config.CAPTURE_PRUNE
+
+
+def _capture_deps(stream):
+    import ctypes
+    from . import _lib
+    buf = (ctypes.c_void_p * 64)()
+    n = _lib.lib().unast_capture_get_deps(stream.cuda_stream, buf, 64)
+    return None if n < 0 else tuple(buf[i] for i in range(n))
+
+
+def _prune(stream, origin, keep):
+    import ctypes
+    from . import _lib
+    buf = (ctypes.c_void_p * max(len(keep), 1))(*keep)
+    n = _lib.lib().unast_capture_prune(stream.cuda_stream, origin.cuda_stream, buf, len(keep))
+    if n < 0:
+        raise RuntimeError("unast_capture_prune failed: %s" % _lib.lib().unast_last_error().decode())
+    PRUNED[0] += n
 
 
 def on_stream(name):
@@ -320,6 +348,16 @@ class _Segment(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, *gouts):
         cur = torch.cuda.current_stream() if _Streams.used else None
+        origin = _CaptureWaits.origin
+        prune = origin is not None and cur is not None and cur != origin and _prune_on()
+        if prune:
+            # Inside a capture this stream has just synced with the origin for its incoming gradients and inherited the producers of every
+            # hand-off the origin ever relayed; keep those of ITS gradients only (include/unast_hip.h unast_capture_prune).
+            keep = []
+            for g in gouts:
+                if g is not None:
+                    keep += _GradTail.get(g.untyped_storage().data_ptr(), ())
+            _prune(cur, origin, keep)
         for o, g in zip(ctx.out_vars, gouts):
             if g is not None and g.dtype != torch.float32:
                 g = g.float()
@@ -330,6 +368,14 @@ class _Segment(torch.autograd.Function):
         if ctx.hook is not None:
             ctx.hook[2](ctx.hook[1], ctx.hook[3])      # ddp.segment_backward(bucket, store): this call's gradients are enqueued
         grads = tuple((v.g if isinstance(v, Var) else None) for v in ctx.in_vars)
+        if origin is not None and cur is not None and _prune_on():
+            tail = _capture_deps(cur)                  # what produced these gradients, for the segment that receives them
+            if tail:
+                for gr in grads:
+                    if gr is not None:                  # (a union: two producers may fill row blocks of one buffer, and the allocator reuses addresses)
+                        ptr = gr.untyped_storage().data_ptr()
+                        old = _GradTail.get(ptr)
+                        _GradTail[ptr] = tail if not old else tuple(set(old) | set(tail))
         ctx.tape = ctx.in_vars = ctx.out_vars = None
         return (None, None) + grads
 
