@@ -352,6 +352,18 @@ int unast_panel_gemm(const float* A, int lda, const void* w_planes, int64_t plan
  * Plane layout: 1-KB sub-tiles of 16 n x 32 k at ((n / 16) * ksteps + k / 32) * 1024, inside a sub-tile 16-byte units
  * [(k % 32) / 8][n % 16] of 8 consecutive k; hi = RNE_bf16(x), lo = RNE_bf16(x - hi); padding is zero. */
 int unast_retile_weights(const float* src_base, void* dst_base, const void* descs_dev, int ndesc, hipStream_t stream);
+/* The input-gradient GEMM that ends a sub-layer's backward with the PREVIOUS sub-layer's LayerNorm backward in its epilogue
+ * (torch post-LN layers, /root/reference/src/module.py:273-274, 286-287): dy = R + A W^T (A [M,K], K > 256, W^T as tiled planes, N = 256),
+ * dz = LayerNorm-backward(dy; z, mean, rstd, gamma) -> dz, dropout(dz) -> dz_drop (NULL: none), column sums of dy xhat / dy per 128-row
+ * panel -> part (unast_panel_gemm_lnbwd_ws_floats(M) floats; NULL: none), reduced into dgamma / dbeta by
+ * unast_layernorm_partials_finalize(part, ceil(M / 128), 256, ...).  Replaces unast_panel_gemm + unast_layernorm_bwd where the row-panel
+ * kernel serves the shape. */
+int unast_panel_gemm_lnbwd(const float* A, int lda, const void* w_planes, int64_t plane_bytes, int M, int K, const float* R, int ldr,
+                           const float* z, int ldz, const float* mean, const float* rstd, const float* gamma,
+                           float* dz, int lddz, float* dz_drop, int lddrop, float* part, int64_t part_floats,
+                           float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream);
+int64_t unast_panel_gemm_lnbwd_ws_floats(int M);
+int unast_layernorm_partials_finalize(const float* part, int nblk, int C, float* dgamma, float* dbeta, hipStream_t stream);
 /* Writes n <= 16 32-bit words (read from HOST memory at call time, passed by value in the kernel arguments) to device memory:
  * refreshes the block a captured step reads (RNG epoch of unast_set_rng_epoch, dev_hyper triples of unast_adamw) once per
  * replay; stands where the reference's Python passes lr / step to torch.optim (src/train.py:361, 654-655). */

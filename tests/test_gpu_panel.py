@@ -210,6 +210,45 @@ def test_k_streamed_layernorm_epilogue(M):
         assert float((y0 - y1).abs().max()) < 5e-6 and float((m0 - m1).abs().max()) < 1e-6 and float(((r0 - r1) / r0).abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("M,K", [(300, 768), (1000, 1024), (129, 320), (4096, 768)])
+def test_layernorm_backward_in_the_input_gradient_epilogue(M, K, monkeypatch):
+    """ops.linear_dgrad_lnbwd (csrc/panel.hip kpanel_kernel<2>): dz = LayerNorm-backward(R + dy W), dropout(dz), dgamma, dbeta in one launch
+    == linear_dgrad followed by layernorm_bwd (the kernels the golden tests pin), to fp32 rounding; the dropout masks are the same bits."""
+    from unast_amd import config, ops
+    from unast_amd.planes import Planes
+    monkeypatch.setattr(config, "PANEL_MIN_ROWS", 1)
+    torch.manual_seed(M + K)
+    E = 256
+    dy = torch.randn(M, K, device=D)
+    W = torch.randn(K, E, device=D) * 0.05                      # stored [out = K][in = E] weight of the forward GEMM; dx = dy @ W
+    R = torch.randn(M, E, device=D)
+    z = torch.randn(M, E, device=D) * 2 + 0.3
+    gamma = torch.rand(E, device=D) + 0.5
+    mean = z.mean(1).contiguous(); rstd = (z.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    pl = Planes([W], transposed=True)
+    monkeypatch.setattr(ops, "_weight_planes", lambda w, transposed=False: pl.ref(0) if transposed and w.data_ptr() == W.data_ptr() else None)
+    for p_drop, use_r in ((0.0, True), (0.2, True), (0.2, False)):
+        Rr = R if use_r else None
+        dx = torch.empty(M, E, device=D)
+        ops.linear_dgrad(dy, W, dx, R=Rr)
+        dz0 = torch.empty(M, E, device=D); dzd0 = torch.empty(M, E, device=D) if p_drop > 0 else None
+        dg0 = torch.full((E,), 0.25, device=D); db0 = torch.full((E,), -0.5, device=D)
+        ops.layernorm_bwd(dx, z, gamma, mean, rstd, dz0, dzd0, dg0, db0, drop_p=p_drop, seed=13, stream_id=5)
+        dz1 = torch.full((M + 3, E), 7.0, device=D); dzd1 = torch.full((M + 3, E), 7.0, device=D) if p_drop > 0 else None
+        dg1 = torch.full((E,), 0.25, device=D); db1 = torch.full((E,), -0.5, device=D)
+        before = ops.LNBWD_FUSED[0]
+        assert ops.linear_dgrad_lnbwd(dy, W, Rr, z, mean, rstd, gamma, dz1[:M], None if dzd1 is None else dzd1[:M], dg1, db1, drop_p=p_drop, seed=13, stream_id=5)
+        assert ops.LNBWD_FUSED[0] == before + 1
+        from unast_amd.engine import join_streams
+        join_streams(); torch.cuda.synchronize()
+        sc = float(dz0.abs().max())
+        assert float((dz0 - dz1[:M]).abs().max()) < 2e-5 * sc, (p_drop, use_r)
+        assert bool((dz1[M:] == 7.0).all())
+        if p_drop > 0:
+            assert torch.equal(dzd0 == 0, dzd1[:M] == 0) and float((dzd0 - dzd1[:M]).abs().max()) < 3e-5 * sc
+        assert float((dg0 - dg1).abs().max()) < 2e-5 * float(dg0.abs().max()) and float((db0 - db1).abs().max()) < 2e-5 * float(db0.abs().max())
+
+
 def test_train_step_with_and_without_the_panel_kernel_agree():
     """Two whole train steps (ae + sp + d sub-steps, clip + AdamW) with the row-panel kernel forced on for every eligible GEMM against the same
     steps on the tile GEMM."""

@@ -94,6 +94,8 @@ def test_full_step_matches_reference_golden(golden_dir, name, panel_rows, joint,
     losses = defaultdict(list)
     model.train()
     train.freeze_model_parameters(model.discriminator)
+    from unast_amd import ops
+    fused_before = ops.LNBWD_FUSED[0]
     if joint:
         assert train.joint_generator_phase(args, batch, batch)
         train.train_gen_joint_step(losses, model, batch, batch, 0, 2, args)
@@ -101,6 +103,9 @@ def test_full_step_matches_reference_golden(golden_dir, name, panel_rows, joint,
         train.train_ae_step(losses, model, batch, 0, 2, args)
         train.train_sp_step(losses, model, batch, 0, 2, args)
     model.expose_grads()
+    # with the row gate at one row the stacks' LayerNorm backwards ran in the epilogue of the input-gradient GEMMs (ops.linear_dgrad_lnbwd):
+    # the fused form is compared with the reference's gradients here, like everything else
+    assert (ops.LNBWD_FUSED[0] > fused_before) == (panel_rows == 1), (ops.LNBWD_FUSED[0] - fused_before, panel_rows)
     gn = np.array([params[n].grad.double().norm().item() if params[n].grad is not None else -1.0 for n in names])
     ref = g["gen_grad_norms"]
     assert np.array_equal(gn < 0, ref < 0), "set of parameters without gradient differs from the reference"

@@ -57,6 +57,10 @@ DETERMINISTIC_SUMS = os.environ.get("UNAST_DETERMINISTIC_SUMS", "0") == "1"
 # are not the producers of its own incoming gradients (engine._Segment._backward; include/unast_hip.h unast_capture_prune).  0 = round-2 form.
 CAPTURE_PRUNE = os.environ.get("UNAST_CAPTURE_PRUNE", "1") != "0"
 
+# LayerNorm backward in the epilogue of the input-gradient GEMM that produces its dy (ops.linear_dgrad_lnbwd; inside the encoder / decoder
+# stacks, where a sub-layer's output has the next sub-layer as its only consumer).  0 = GEMM + stand-alone LayerNorm backward.
+PANEL_LNBWD = os.environ.get("UNAST_PANEL_LNBWD", "1") != "0"
+
 # Weight gradients of one backward closure (an attention sub-layer's out-proj + in-proj, an FFN's two linears, ...) go out as
 # ONE grouped launch (csrc/gemm.hip gemm_group_kernel) instead of one split-K launch + one reduction each; 0 = one by one.
 WGRAD_GROUP = os.environ.get("UNAST_WGRAD_GROUP", "1") != "0"

@@ -455,6 +455,13 @@ extern "C" int unast_layernorm_bwd_finalize(const float* ws, int64_t ws_floats, 
     return unast_check_launch("unast_layernorm_bwd_finalize");
 }
 
+// The same reduction for partials written by another kernel (unast_panel_gemm_lnbwd: one [2][C] row per 128-row panel).
+extern "C" int unast_layernorm_partials_finalize(const float* part, int nblk, int C, float* dgamma, float* dbeta, hipStream_t stream) {
+    UNAST_REQUIRE(part && dgamma && dbeta && nblk > 0 && C > 0 && C <= 1024, "unast_layernorm_partials_finalize: bad arguments");
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, part, nblk, C, dgamma, dbeta);
+    return unast_check_launch("unast_layernorm_partials_finalize");
+}
+
 static int colsum_geometry(int rows, int C, int* blocks, int* rpb) {
     if ((C & 3) != 0 || C > 1024 || C <= 0) return -1;
     int b = grid_for(rows, 64, 1024);

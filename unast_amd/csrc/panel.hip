@@ -36,6 +36,7 @@ struct PanelParams {
     int act; uint32_t drop_thresh; float drop_scale; uint32_t seed, stream;
     int out_split;
     const float* gamma; const float* beta; float* Y; int ldy; float* mean; float* rstd; float eps;
+    const float* Z; int ldz; float* part;           // LayerNorm-BACKWARD epilogue of the K-streamed kernel (kpanel_kernel<2>): saved pre-norm rows, column partials
     unsigned long long* gate_bits;                  // keep bits of an [M,N] activation: written when act == 1, read (as the gate) otherwise
     unsigned long long* stamps;                     // diagnostic build only (-DPANEL_STAMPS): per-wave cycle sums per loop phase
 };
@@ -908,7 +909,99 @@ __global__ __launch_bounds__(1024, 4) void kpanel_kernel(const PanelParams p) {
 #endif
     __syncthreads();                                      // (bias words visible whatever KG; the ring is idle: every DMA has been waited for)
     // lane holds C[m = m_wave + 16 rt + l15][n = n_wg + 64 ch + 16 ct + 4 g .. + 3]
-    if constexpr (!LN) {
+    if constexpr (LN == 2) {
+        // LayerNorm BACKWARD in the epilogue (round 4).  The GEMM is the input-gradient contraction that ends a sub-layer's backward,
+        // dy = R + acc is the complete gradient of the PREVIOUS sub-layer's LayerNorm output, and the workgroup holds whole rows of it:
+        //   g = dy gamma, xhat = (z - mean) rstd, dz = rstd (g - mean_row(g) - xhat mean_row(g xhat)),
+        // dz -> C, dropout(dz) -> Y (the gradient of that sub-layer's dropped branch), column sums of dy xhat / dy over the panel's rows
+        // -> part[panel][0 / 1][256] (summed by ln_bwd_finalize_kernel).  What the stand-alone kernel (norm.hip layernorm_bwd_kernel)
+        // computes, in the same formulas; its launch, its read of dy and the GEMM's write of dy disappear.
+        float* const red = reinterpret_cast<float*>(smem);              // the rings are idle: [2][4][128] row partials, then [2][4][256] column partials
+        float xh[2][4][4], mu[2], rs[2], s1[2], s2[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int mr = m_wave + 16 * rt + l15, m = min(mr, p.M - 1);
+            mu[rt] = p.mean[m]; rs[rt] = p.rstd[m];
+            s1[rt] = 0.f; s2[rt] = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int n = 64 * ch + 16 * ct + 4 * g;
+                const float4 r4 = p.R ? *reinterpret_cast<const float4*>(p.R + (size_t)m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 z4 = *reinterpret_cast<const float4*>(p.Z + (size_t)m * p.ldz + n);
+                const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + n);
+                const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w}, gm[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dy = mr < p.M ? acc[rt][ct][r] + rr[r] : 0.f;          // rows beyond M add nothing to the column sums
+                    const float x = (zz[r] - mu[rt]) * rs[rt];
+                    const float gg = dy * gm[r];
+                    acc[rt][ct][r] = dy; xh[rt][ct][r] = x;
+                    s1[rt] += gg; s2[rt] += gg * x;
+                }
+            }
+            s1[rt] += __shfl_xor(s1[rt], 16, 64); s1[rt] += __shfl_xor(s1[rt], 32, 64);
+            s2[rt] += __shfl_xor(s2[rt], 16, 64); s2[rt] += __shfl_xor(s2[rt], 32, 64);
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                red[ch * 128 + 32 * rg + 16 * rt + l15] = s1[rt];
+                red[512 + ch * 128 + 32 * rg + 16 * rt + l15] = s2[rt];
+            }
+        }
+        __syncthreads();
+        float cg[4][4], cb[4][4];                          // column partials over this lane's two rows
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { cg[ct][r] = 0.f; cb[ct][r] = 0.f; }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int r0 = 32 * rg + 16 * rt + l15, m = m_wg + r0;
+            const float c1 = ((red[r0] + red[128 + r0]) + (red[256 + r0] + red[384 + r0])) * (1.f / 256.f);
+            const float c2 = ((red[512 + r0] + red[640 + r0]) + (red[768 + r0] + red[896 + r0])) * (1.f / 256.f);
+            uint32_t rkey = 0;
+            if (p.drop_thresh) rkey = pcg_hash((uint32_t)min(m, p.M - 1) + rbase);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int n = 64 * ch + 16 * ct + 4 * g;
+                const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + n);         // (again: 32 registers less than keeping dy gamma)
+                const float gm[4] = {g4.x, g4.y, g4.z, g4.w};
+                float o[4], od[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = rs[rt] * (acc[rt][ct][r] * gm[r] - c1 - xh[rt][ct][r] * c2);
+                    od[r] = (!p.drop_thresh || rng_keep(rkey, (uint32_t)(n + r), p.drop_thresh)) ? o[r] * p.drop_scale : 0.f;
+                    cg[ct][r] += acc[rt][ct][r] * xh[rt][ct][r];
+                    cb[ct][r] += acc[rt][ct][r];
+                }
+                if (m < p.M) {
+                    *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (p.Y) *reinterpret_cast<float4*>(p.Y + (size_t)m * p.ldy + n) = make_float4(od[0], od[1], od[2], od[3]);
+                }
+            }
+        }
+        __syncthreads();                                   // the row partials have been read: `red` becomes [2][4 row groups][256 columns]
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = cg[ct][r], b = cb[ct][r];        // sum over the 16 rows of the lane row (DPP-free form: four butterfly steps)
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (l15 == 0) {
+                    const int n = 64 * ch + 16 * ct + 4 * g + r;
+                    red[rg * 256 + n] = a;
+                    red[1024 + rg * 256 + n] = b;
+                }
+            }
+        __syncthreads();
+        if (p.part && t < 512) {
+            const int q = t >> 8, n = t & 255;
+            const float* rp = red + q * 1024 + n;
+            p.part[((size_t)blockIdx.x * 2 + q) * 256 + n] = (rp[0] + rp[256]) + (rp[512] + rp[768]);
+        }
+    } else if constexpr (!LN) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int m = m_wave + 16 * rt + l15;
@@ -1014,6 +1107,33 @@ static void panel_launch(const PanelParams& p, int rows, int ln, hipStream_t s) 
         if (rows == 128) hipLaunchKernelGGL((panel_kernel<KSTEPS, 2, 0, 8>), grid, dim3(512), 0, s, p);
         else             hipLaunchKernelGGL((panel_kernel<KSTEPS, 1, 0, 8>), grid, dim3(512), 0, s, p);
     }
+}
+
+// dz = LayerNorm-backward(R + A W^T) and its by-products in ONE launch (kpanel_kernel<2>): see the epilogue's comment.  K > 256, N = 256.
+extern "C" int64_t unast_panel_gemm_lnbwd_ws_floats(int M) { return (int64_t)((M + 127) / 128) * 2 * 256; }
+
+extern "C" int unast_panel_gemm_lnbwd(const float* A, int lda, const void* w_planes, int64_t plane_bytes, int M, int K, const float* R, int ldr,
+                                      const float* z, int ldz, const float* mean, const float* rstd, const float* gamma,
+                                      float* dz, int lddz, float* dz_drop, int lddrop, float* part, int64_t part_floats,
+                                      float drop_p, unsigned int seed, unsigned int stream_id, hipStream_t stream) {
+    UNAST_REQUIRE(A && w_planes && z && mean && rstd && gamma && dz && M > 0, "unast_panel_gemm_lnbwd: null pointer");
+    UNAST_REQUIRE(K > 256 && (K & 63) == 0 && (lda & 3) == 0 && (lddz & 3) == 0 && (ldz & 3) == 0 && (!R || (ldr & 3) == 0) && (!dz_drop || (lddrop & 3) == 0) &&
+                  ((((uintptr_t)A) | ((uintptr_t)dz) | ((uintptr_t)w_planes) | ((uintptr_t)z) | ((uintptr_t)R) | ((uintptr_t)dz_drop) | ((uintptr_t)gamma)) & 15) == 0,
+                  "unast_panel_gemm_lnbwd: needs K > 256, K %% 64 == 0, 16-byte row strides and aligned operands (K=%d)", K);
+    UNAST_REQUIRE(!part || part_floats >= unast_panel_gemm_lnbwd_ws_floats(M), "unast_panel_gemm_lnbwd: partials buffer too small");
+    UNAST_REQUIRE(dz_drop || drop_p <= 0.f, "unast_panel_gemm_lnbwd: dropout needs the second output");
+    {
+        const size_t ld_max = (size_t)std::max(std::max(lda, lddz), std::max(std::max(R ? ldr : 0, ldz), dz_drop ? lddrop : 0));
+        UNAST_REQUIRE(((size_t)M + 127) / 128 * 128 * ld_max * 4 < (size_t)0x7FFFFFF0u, "unast_panel_gemm_lnbwd: operand exceeds the 2 GiB a buffer descriptor addresses");
+    }
+    PanelParams q = {};
+    q.stamps = nullptr;
+    q.A = A; q.lda = lda; q.W = (const unsigned char*)w_planes; q.plane_bytes = (size_t)plane_bytes; q.C = dz; q.ldc = lddz; q.M = M; q.N = 256; q.K = K; q.ncg = 4;
+    q.R = R; q.ldr = ldr; q.Z = z; q.ldz = ldz; q.mean = const_cast<float*>(mean); q.rstd = const_cast<float*>(rstd); q.gamma = gamma;
+    q.Y = dz_drop; q.ldy = lddrop; q.part = part;
+    q.drop_thresh = dz_drop ? drop_threshold(drop_p) : 0u; q.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; q.seed = seed; q.stream = stream_id;
+    hipLaunchKernelGGL((kpanel_kernel<2>), dim3((M + 127) / 128, 1), dim3(1024), 0, stream, q);
+    return unast_check_launch("unast_panel_gemm_lnbwd");
 }
 
 // Diagnostic builds (-DPANEL_STAMPS, tools/panel_stamps.py): device buffer of 8 x 8 x workgroups uint64 that receives per-wave cycle sums.

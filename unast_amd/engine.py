@@ -281,12 +281,16 @@ def on_stream(name):
 
 
 class Var:
-    """An activation and its gradient slot."""
-    __slots__ = ("v", "g")
+    """An activation and its gradient slot.  ln / pre (functional.py, the post-LN stacks): the LayerNorm that produced `v` and whose
+    only consumer is the next sub-layer -- that sub-layer's backward may then run the LayerNorm's backward in the epilogue of its last
+    GEMM and leave the result in `pre` = (dz, dz_dropped) instead of a gradient in `g`."""
+    __slots__ = ("v", "g", "ln", "pre")
 
     def __init__(self, v, g=None):
         self.v = v
         self.g = g
+        self.ln = None
+        self.pre = None
 
 
 def acc(var, grad):

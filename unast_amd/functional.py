@@ -61,6 +61,40 @@ def _layernorm(cx, tape, z, pre, x_res_grad_sink):
     return y, mean, rstd
 
 
+def _ln_backward(cx, out, z, mean, rstd, pre_norm, p, seed, stream_id):
+    """(dz, dz_dropped-or-dz) of the LayerNorm that produced `out`: already there when the consuming sub-layer's last GEMM ran it in its
+    epilogue (out.pre, _input_grad below), otherwise the stand-alone kernel on out.g."""
+    if out.pre is not None:
+        dz, dzd = out.pre
+        out.pre = None
+        return dz, (dzd if p > 0 else dz)
+    st = cx.st
+    dz = _empty(*z.shape, like=z)
+    dzd = _empty(*z.shape, like=z) if p > 0 else None
+    ops.layernorm_bwd(out.g, z, cx.P[pre_norm + "weight"], mean, rstd, dz, dzd, st.g(pre_norm + "weight"), st.g(pre_norm + "bias"),
+                      drop_p=p, seed=seed, stream_id=stream_id)
+    return dz, (dzd if p > 0 else dz)
+
+
+def _input_grad(cx, x, dy2d, W, dz_res):
+    """The last GEMM of a sub-layer's backward: dx = dz_res + dy2d @ W, accumulated into x -- or, when x is the output of a LayerNorm
+    inside the stack whose only consumer this sub-layer is (x.ln, set by the stack loops) and nothing else has contributed to x.g, that
+    LayerNorm's backward in the same launch (ops.linear_dgrad_lnbwd), its result left in x.pre for the producing sub-layer's closure."""
+    ln = x.ln
+    if ln is not None and x.g is None and x.pre is None:
+        z, mean, rstd, pre_norm, p, seed, sid = ln
+        st = cx.st
+        dz = _empty(*z.shape, like=z)
+        dzd = _empty(*z.shape, like=z) if p > 0 else None
+        if ops.linear_dgrad_lnbwd(dy2d, W, dz_res, z, mean, rstd, cx.P[pre_norm + "weight"], dz, dzd, st.g(pre_norm + "weight"), st.g(pre_norm + "bias"),
+                                  drop_p=p, seed=seed, stream_id=sid):
+            x.pre = (dz, dzd)
+            return
+    dx = _empty(dy2d.shape[0], W.shape[1], like=dy2d)
+    ops.linear_dgrad(dy2d, W, dx, R=dz_res)
+    acc(x, dx)
+
+
 def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, Tk, H, drop, pad_free_grads=False):
     """y = LN(x + dropout(MHA(x, mem or x)))  with attention-probability dropout `drop` as well.
     x: Var [B*Tq, E]; mem: Var [B*Tk, E] or None for self-attention."""
@@ -94,19 +128,17 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
     if tape is not None:
         seed = cx.seed
 
+        out.ln = (z, mean, rstd, pre_norm, p, seed, s_out)      # (used only if a stack loop declares the next sub-layer the sole consumer: _sole)
+
         def bwd():
-            if out.g is None:
+            if out.g is None and out.pre is None:
                 return
             with ops.wgrad_batch():            # out-proj + in-proj weight gradients: one grouped launch at the end
                 bwd_body()
 
         def bwd_body():
             st = cx.st
-            dz = _empty(Nq, E, like=z)
-            dzd = _empty(Nq, E, like=z) if p > 0 else None
-            ops.layernorm_bwd(out.g, z, cx.P[pre_norm + "weight"], mean, rstd, dz, dzd, st.g(pre_norm + "weight"), st.g(pre_norm + "bias"),
-                              drop_p=p, seed=seed, stream_id=s_out)
-            da = dzd if p > 0 else dz
+            dz, da = _ln_backward(cx, out, z, mean, rstd, pre_norm, p, seed, s_out)
             gWo = st.g(pre_attn + "out_proj.weight")
             if gWo is not None:
                 ops.linear_wgrad(da, O, gWo, db=st.g(pre_attn + "out_proj.bias"))
@@ -120,8 +152,7 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
                              drop_p=p, seed=seed, stream_id=s_attn, qkv_split=ps, lens_q=lens_k if (pad_free_grads and config.ENC_SKIP_PAD_GRADS) else None)
                 if gW is not None:
                     ops.linear_wgrad(dqkv, x.v, gW, db=gb)
-                dx = _empty(Nq, E, like=z)
-                ops.linear_dgrad(dqkv, W, dx, R=dz)
+                _input_grad(cx, x, dqkv, W, dz)
             else:
                 dq = _empty(Nq, E, like=z)
                 dkv = _empty(Nk, 2 * E, like=z)
@@ -130,12 +161,10 @@ def attn_sublayer(cx, tape, x, mem, lens_k, causal, pre_attn, pre_norm, B, Tq, T
                 if gW is not None:
                     ops.linear_wgrad(dq, x.v, gW[:E], db=gb[:E])
                     ops.linear_wgrad(dkv, mem.v, gW[E:], db=gb[E:])
-                dx = _empty(Nq, E, like=z)
-                ops.linear_dgrad(dq, W[:E], dx, R=dz)
+                _input_grad(cx, x, dq, W[:E], dz)           # (contraction over 256: the K-streamed kernel does not serve it; plain path)
                 dmem = _empty(Nk, E, like=z)
                 ops.linear_dgrad(dkv, W[E:], dmem)
                 acc(mem, dmem)
-            acc(x, dx)
         tape.record(bwd)
     return out
 
@@ -172,16 +201,14 @@ def cross_attn_sublayer_pair(cx, tape, x2, mems, lens_ks, Tks, pre_attn, pre_nor
     if tape is not None:
         seed = cx.seed
 
+        out.ln = (z, mean, rstd, pre_norm, p, seed, s_out)
+
         def bwd():
-            if out.g is None:
+            if out.g is None and out.pre is None:
                 return
             with ops.wgrad_batch():
                 st = cx.st
-                dz = _empty(2 * N, E, like=z)
-                dzd = _empty(2 * N, E, like=z) if p > 0 else None
-                ops.layernorm_bwd(out.g, z, cx.P[pre_norm + "weight"], mean, rstd, dz, dzd, st.g(pre_norm + "weight"), st.g(pre_norm + "bias"),
-                                  drop_p=p, seed=seed, stream_id=s_out)
-                da = dzd if p > 0 else dz
+                dz, da = _ln_backward(cx, out, z, mean, rstd, pre_norm, p, seed, s_out)
                 gWo = st.g(pre_attn + "out_proj.weight")
                 if gWo is not None:
                     ops.linear_wgrad(da, O2, gWo, db=st.g(pre_attn + "out_proj.bias"))
@@ -203,9 +230,7 @@ def cross_attn_sublayer_pair(cx, tape, x2, mems, lens_ks, Tks, pre_attn, pre_nor
                 if gW is not None:
                     ops.linear_wgrad(dkvs[0], mems[0].v, gW[E:], db=gb[E:])
                     ops.linear_wgrad(dq2, x2.v, gW[:E], db=gb[:E])
-                dx = _empty(2 * N, E, like=z)
-                ops.linear_dgrad(dq2, W[:E], dx, R=dz)
-                acc(x2, dx)
+                _input_grad(cx, x2, dq2, W[:E], dz)          # (contraction over 256: plain path)
             # the second memory's K/V weight gradient accumulates into the SAME rows of in_proj_weight as the first's: the problems of a
             # grouped launch run side by side, so it goes out on its own, behind the group (same stream: ops keeps a gradient buffer's stream)
             gW = cx.st.g(pre_attn + "in_proj_weight")
@@ -223,6 +248,7 @@ def decoder_stack_pair(cx, tape, x2, lens_q2, mems, lens_ks, Tks, pre, L, B, Tq,
         x2 = attn_sublayer(cx, tape, x2, None, lens_q2, True, lp + "self_attn.", lp + "norm1.", 2 * B, Tq, Tq, H, drop)
         x2 = cross_attn_sublayer_pair(cx, tape, x2, mems, lens_ks, Tks, lp + "multihead_attn.", lp + "norm2.", B, Tq, H, drop)
         x2 = ffn_sublayer(cx, tape, x2, lp, lp + "norm3.", drop)
+    x2.ln = None                # the stack's output has consumers outside it: its LayerNorm backward stays a launch of its own
     return x2
 
 
@@ -282,19 +308,17 @@ def ffn_sublayer(cx, tape, x, pre, pre_norm, drop):
     if tape is not None:
         seed = cx.seed
 
+        out.ln = (z, mean, rstd, pre_norm, p, seed, s2)
+
         def bwd():
-            if out.g is None:
+            if out.g is None and out.pre is None:
                 return
             with ops.wgrad_batch():            # linear2 + linear1 weight gradients: one grouped launch at the end
                 bwd_body()
 
         def bwd_body():
             st = cx.st
-            dz = _empty(N, E, like=z)
-            dzd = _empty(N, E, like=z) if p > 0 else None
-            ops.layernorm_bwd(out.g, z, cx.P[pre_norm + "weight"], mean, rstd, dz, dzd, st.g(pre_norm + "weight"), st.g(pre_norm + "bias"),
-                              drop_p=p, seed=seed, stream_id=s2)
-            da = dzd if p > 0 else dz
+            dz, da = _ln_backward(cx, out, z, mean, rstd, pre_norm, p, seed, s2)
             g2 = st.g(pre + "linear2.weight")
             if g2 is not None:
                 ops.linear_wgrad(da, h, g2, db=st.g(pre + "linear2.bias"))
@@ -307,9 +331,7 @@ def ffn_sublayer(cx, tape, x, pre, pre_norm, drop):
             g1 = st.g(pre + "linear1.weight")
             if g1 is not None:
                 ops.linear_wgrad(du, x.v, g1, db=st.g(pre + "linear1.bias"))
-            dx = _empty(N, E, like=z)
-            ops.linear_dgrad(du, W1, dx, R=dz)
-            acc(x, dx)
+            _input_grad(cx, x, du, W1, dz)
         tape.record(bwd)
     return out
 
@@ -320,6 +342,7 @@ def encoder_stack(cx, tape, x, lens, pre, L, B, T, H, drop):
         lp = "%s%d." % (pre, i)
         x = attn_sublayer(cx, tape, x, None, lens, False, lp + "self_attn.", lp + "norm1.", B, T, T, H, drop, pad_free_grads=True)
         x = ffn_sublayer(cx, tape, x, lp, lp + "norm2.", drop)
+    x.ln = None                 # the stack's output has consumers outside it (decoder memory, discriminator): plain LayerNorm backward
     return x
 
 
@@ -330,6 +353,7 @@ def decoder_stack(cx, tape, x, lens_q, mem, lens_k, pre, L, B, Tq, Tk, H, drop):
         x = attn_sublayer(cx, tape, x, None, lens_q, True, lp + "self_attn.", lp + "norm1.", B, Tq, Tq, H, drop)
         x = attn_sublayer(cx, tape, x, mem, lens_k, False, lp + "multihead_attn.", lp + "norm2.", B, Tq, Tk, H, drop)
         x = ffn_sublayer(cx, tape, x, lp, lp + "norm3.", drop)
+    x.ln = None
     return x
 
 

@@ -204,6 +204,39 @@ def linear_dgrad(dy2d, W, dx, R=None, G=None, gate_scale=1.0, beta=0, out_split=
     return dx
 
 
+LNBWD_FUSED = [0]         # launches of the fused form below (tests look at it)
+
+
+def linear_dgrad_lnbwd(dy2d, W, R, z, mean, rstd, gamma, dz, dz_drop, dgamma, dbeta, drop_p=0.0, seed=0, stream_id=0):
+    """The input-gradient GEMM that ends a sub-layer's backward together with the PREVIOUS sub-layer's LayerNorm backward:
+    dz = LNbwd(R + dy2d @ W; z, mean, rstd, gamma), dz_drop = dropout(dz), dgamma / dbeta += column sums -- one launch of the K-streamed
+    row-panel kernel (csrc/panel.hip kpanel_kernel<2>) instead of linear_dgrad + layernorm_bwd.  Returns False (and does nothing) when the
+    kernel does not serve the shape: contraction dy2d.shape[1] > 256 and a multiple of 64, 256 output columns, at least
+    config.PANEL_MIN_ROWS rows, tiled planes of W^T, 16-byte operands."""
+    M, N = dy2d.shape
+    if not (config.PANEL_LNBWD and W.shape[1] == 256 and N > 256 and W.stride(1) == 1 and z.shape[1] == 256 and
+            _panel_ok(M, N, dy2d, dz, R, z, dz_drop, N=256) and gamma.data_ptr() % 16 == 0):
+        return False
+    wp = _weight_planes(W, transposed=True)
+    if wp is None:
+        return False
+    part, part_n = None, 0
+    if dgamma is not None:
+        part_n = lib().unast_panel_gemm_lnbwd_ws_floats(M)
+        part = torch.empty(part_n, dtype=torch.float32, device=dy2d.device)
+    PANEL_LAUNCHES[1] += 1
+    LNBWD_FUSED[0] += 1
+    check(lib().unast_panel_gemm_lnbwd(_p(dy2d), dy2d.stride(0), wp[0], wp[1], M, N, _p(R), R.stride(0) if R is not None else 0,
+                                       _p(z), z.stride(0), _p(mean), _p(rstd), _p(gamma), _p(dz), dz.stride(0),
+                                       _p(dz_drop), dz_drop.stride(0) if dz_drop is not None else 0, _p(part), part_n,
+                                       drop_p if dz_drop is not None else 0.0, seed & 0xFFFFFFFF, stream_id, _stream()), "unast_panel_gemm_lnbwd")
+    if dgamma is not None:      # the reduction of the parameter-gradient partials is off the backward chain: companion stream
+        nblk = (M + 127) // 128
+        _on_wgrad_stream(lambda: check(lib().unast_layernorm_partials_finalize(_p(part), nblk, 256, _p(dgamma), _p(dbeta), _stream()),
+                                       "unast_layernorm_partials_finalize"), M if config.LN_FINALIZE_OFFLOAD else 0, dgamma.data_ptr(), part)
+    return True
+
+
 # Set by engine.side_streams: returns the companion stream for weight gradients issued from the current stream, or None.
 WGRAD_SIDE = None
 
