@@ -70,7 +70,8 @@ class OpTimer:
                 e0.record()
                 r = __f(*a, **k)
                 e1.record()
-                self.events[__n].append((e0, e1, self._key(__n, a, k)))
+                if __n != "linear_dgrad_lnbwd" or r:               # (returns False, having launched nothing, where the kernel does not serve the shape)
+                    self.events[__n].append((e0, e1, self._key(__n, a, k)))
                 return r
             setattr(self.ops, n, wrapped)
         return self
@@ -86,6 +87,10 @@ class OpTimer:
             return tuple(int(x) for x in a[idx:idx + 5])          # B, H, Tq, Tk, causal
         if n == "wgrad_group":
             return a[0]                                           # ((out, in, tokens, has_bias), ...)
+        if n == "linear_dgrad_lnbwd":
+            # the input-gradient GEMM with a LayerNorm backward in its epilogue (dy2d, W, R, z, mean, rstd, gamma, dz, dz_drop, ...): a row-panel
+            # launch with N = 256 whose epilogue also reads R and z and writes dropout(dz)
+            return (int(a[0].shape[0]), 256, int(a[0].shape[1]), int(a[2] is not None) + 1 + int(a[8] is not None))
         if n == "panel_gemm":
             # (M, N, K, extra [M,N] operands the epilogue reads or writes beyond C: residual, gate, the LayerNorm output)
             A, N = a[0], a[3]
@@ -358,7 +363,7 @@ def main():
     # In-region HIP-event pairs exist only in the eager form (a replayed graph has no per-kernel host hooks) and only with --time-every:
     # they cost ~15 us of host time per launch, enough to make the host the bottleneck.  The roofline figures come from the isolated
     # single-stream steps after the timed region.
-    timed = ["gemm", "wgrad_group", "panel_gemm", "attn_fwd", "attn_bwd"]
+    timed = ["gemm", "wgrad_group", "panel_gemm", "linear_dgrad_lnbwd", "attn_fwd", "attn_bwd"]
     if a.profile_ops:
         timed += ["layernorm_fwd", "layernorm_bwd", "colsum", "bn_fwd", "bn_bwd", "embed_fwd", "embed_bwd", "posenc_fwd", "posenc_bwd", "rowmask",
                   "add_inplace", "add_strided", "specaugment", "disc_gather", "disc_scatter", "speech_loss_fwd", "speech_loss_bwd", "text_loss_fwd",
@@ -394,7 +399,7 @@ def main():
     side = config.SIDE_STREAMS
     config.SIDE_STREAMS = False
     try:
-        with OpTimer(ops, ["gemm", "wgrad_group", "panel_gemm", "attn_fwd", "attn_bwd"]) as ot_iso:
+        with OpTimer(ops, ["gemm", "wgrad_group", "panel_gemm", "linear_dgrad_lnbwd", "attn_fwd", "attn_bwd"]) as ot_iso:
             for i in range(a.iso_steps):
                 train.train_step(losses, model, opt, sched, batches, n_prime + a.warmup + a.steps + i, args)
             sync()
@@ -421,6 +426,10 @@ def main():
             psu = su["panel_gemm"]
             calls += sum(v[0] for v in psu.values()); tot += sum(v[1] for v in psu.values())
             fl += sum(panel_flops(k) * v[0] for k, v in psu.items()); by += sum(panel_bytes(k) * v[0] for k, v in psu.items())
+        if n == "gemm" and "linear_dgrad_lnbwd" in su:       # ... and the input-gradient launches that carry a LayerNorm backward
+            lsu = su["linear_dgrad_lnbwd"]
+            calls += sum(v[0] for v in lsu.values()); tot += sum(v[1] for v in lsu.values())
+            fl += sum(panel_flops(k) * v[0] for k, v in lsu.items()); by += sum(panel_bytes(k) * v[0] for k, v in lsu.items())
         return dict(calls=calls, ms=tot, flops=fl, bytes=by)
     global ATTN_BWD_PRODUCTS, ATTN_BWD_KERNEL
     if not config.ATTN_FUSED_BWD:
