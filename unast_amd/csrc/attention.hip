@@ -40,6 +40,7 @@ struct AttnParams {
     float scale;
     uint32_t drop_thresh; float drop_scale; uint32_t seed, stream;
     int qkv_split;                     // Q, K, V (and dO) arrive in the pre-split operand format (GEMM out_split): no fp32 -> hi/lo conversion here
+    int order;                         // block dispatch order, see xcd_remap
 };
 
 template <int NSPLIT>
@@ -150,11 +151,20 @@ __device__ __forceinline__ void tile_store(const float4 (&r)[NROWS * 16 / NT], u
 // (x fastest) order the nx blocks that sweep the SAME (batch, head) K/V (or Q/dO) land on nx different L2s and each one
 // re-fetches it from HBM (measured: FETCH_SIZE 2.3x the algorithmic bytes).  Here all nx blocks of one (b,h) get linear
 // ids that are equal mod 8.  Placement is a speed matter only; the grid is padded to a multiple of 8 (b,h) groups.
-__device__ __forceinline__ bool xcd_remap(int nx, int nbh, int& x, int& bh) {
+// order = 1: the blocks of ONE position x of all (b,h) of an XCD before those of the next x -- with ragged lengths (800 = 6 x 128 + 32) the
+// short last block of every (b,h) is then dispatched at the END of the launch, where it fills the tail instead of leaving a full block
+// to finish alone (at the price of a (b,h)'s blocks no longer meeting in the L2: its K/V come from the MALL the later times).
+__device__ __forceinline__ bool xcd_remap(int nx, int nbh, int& x, int& bh, int order = 0) {
     const int L = blockIdx.x;
     const int g = L & 7, s = L >> 3;
-    bh = (s / nx) * 8 + g;
-    x = s % nx;
+    if (order) {
+        const int nbh8 = (nbh + 7) >> 3;
+        x = s / nbh8;
+        bh = (s - x * nbh8) * 8 + g;
+    } else {
+        bh = (s / nx) * 8 + g;
+        x = s % nx;
+    }
     return bh < nbh;
 }
 static inline unsigned xcd_grid(int nx, int nbh) { return (unsigned)(((nbh + 7) / 8) * 8 * nx); }
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(128 * (4 / QS), (QS == 1 ? 4 : 2)) void attn_q_kern
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
     int bx, bh;
-    if (!xcd_remap((p.Tq + 127) / 128, p.B * p.H, bx, bh)) return;       // whole workgroup exits (EXEC stays full elsewhere)
+    if (!xcd_remap((p.Tq + 127) / 128, p.B * p.H, bx, bh, p.order)) return;       // whole workgroup exits (EXEC stays full elsewhere)
     if (p.causal) bx = (p.Tq + 127) / 128 - 1 - bx;                     // late query blocks see the most keys: dispatch them first
     const int h = bh % p.H, b = bh / p.H;
     const int qblk = bx * 128;
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n = lane & 31, hi = lane >> 5;
     int bx, bh;
-    if (!xcd_remap((p.Tq + 127) / 128, p.B * p.H, bx, bh)) return;
+    if (!xcd_remap((p.Tq + 127) / 128, p.B * p.H, bx, bh, p.order)) return;
     if (p.causal) bx = (p.Tq + 127) / 128 - 1 - bx;
     const int h = bh % p.H, b = bh / p.H;
     const int qblk = bx * 128;
@@ -691,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const AttnParams p) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
     int bx, bh;
-    if (!xcd_remap((p.Tk + 127) / 128, p.B * p.H, bx, bh)) return;
+    if (!xcd_remap((p.Tk + 127) / 128, p.B * p.H, bx, bh, p.order)) return;
     const int h = bh % p.H, b = bh / p.H;
     const int kblk = bx * 128;
     const int k0 = kblk + wave * 32;
@@ -991,6 +1001,11 @@ static int fill_common(AttnParams& p, const float* Q, int ldq, const float* K, i
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.causal = causal; p.scale = scale;
     p.drop_thresh = drop_threshold(drop_p); p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.seed = seed; p.stream = stream_id;
     p.qkv_split = qkv_split;
+    // position-major dispatch for the causal launches (blocks of unequal work: heaviest positions first, the light ones fill the tail:
+    // forward 131 -> 121 us, one-pass backward 323 -> 299 us at 64 x 4 heads x 800 x 800, 1 430 -> 1 315 at 2 000 x 2 000), head-major for the
+    // others (their forward loses 4-8 % to the lost L2 locality); tools/ab_attn_order.py, UNAST_ATTN_ORDER = 0 / 1 forces one.
+    static const int forced = [] { const char* e = getenv("UNAST_ATTN_ORDER"); return e ? atoi(e) : -1; }();
+    p.order = forced >= 0 ? forced : (causal ? 1 : 0);
     p.lens_q = nullptr;
     p.O = nullptr; p.LSE = nullptr; p.dO = nullptr; p.Delta = nullptr; p.dK = nullptr; p.dV = nullptr; p.ldo = p.lddo = p.lddk = p.lddv = 0;
     return UNAST_OK;
