@@ -1003,7 +1003,7 @@ static int fill_common(AttnParams& p, const float* Q, int ldq, const float* K, i
     p.qkv_split = qkv_split;
     // position-major dispatch for the causal launches (blocks of unequal work: heaviest positions first, the light ones fill the tail:
     // forward 131 -> 121 us, one-pass backward 323 -> 299 us at 64 x 4 heads x 800 x 800, 1 430 -> 1 315 at 2 000 x 2 000), head-major for the
-    // others (their forward loses 4-8 % to the lost L2 locality); tools/ab_attn_order.py, UNAST_ATTN_ORDER = 0 / 1 forces one.
+    // others (their forward loses 4-8 % to the lost L2 locality; head-major with only the short last blocks moved to the end measured equal); tools/ab_attn_order.py, UNAST_ATTN_ORDER = 0 / 1 forces one.
     static const int forced = [] { const char* e = getenv("UNAST_ATTN_ORDER"); return e ? atoi(e) : -1; }();
     p.order = forced >= 0 ? forced : (causal ? 1 : 0);
     p.lens_q = nullptr;
