@@ -317,3 +317,23 @@ def test_weight_plane_plan_geometry():
     d = descs[8]                                                                            # first block of the transposed matrix
     assert (int(d["src_off"]), int(d["ld"]), int(d["transposed"]), int(d["N"]), int(d["K"]), int(d["n0"]), int(d["k0"])) == (81 * 256, 1024, 1, 1024, 256, 0, 0)
     assert int(d["dst_off"]) == placed[1][0] and int(d["plane_bytes"]) == placed[1][1]
+
+
+def test_parity_mode_and_fixed_summation_order_are_separate_switches():
+    """utils.set_deterministic(True) alone (the parity mode of the golden / oracle tests) must NOT select the order-fixed kernels: those tests
+    are to pin the kernels the train step runs with.  fixed_sums=True / False switches config.DETERMINISTIC_SUMS, None leaves it alone."""
+    from unast_amd import config, ops, utils
+    before = config.DETERMINISTIC_SUMS
+    try:
+        config.DETERMINISTIC_SUMS = False
+        utils.set_deterministic(True)
+        assert utils.is_deterministic() and not ops.deterministic_sums()
+        utils.set_deterministic(True, fixed_sums=True)
+        assert ops.deterministic_sums()
+        utils.set_deterministic(False)
+        assert ops.deterministic_sums() and not utils.is_deterministic()          # (None leaves the sums switch as it is)
+        utils.set_deterministic(False, fixed_sums=False)
+        assert not ops.deterministic_sums()
+    finally:
+        config.DETERMINISTIC_SUMS = before
+        utils.set_deterministic(False)
